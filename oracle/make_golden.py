@@ -1,0 +1,156 @@
+"""Generate tests/golden/*.npz from the reference's OWN modules (run in the build container only).
+
+    python -m oracle.make_golden
+
+TEST INFRASTRUCTURE.  Imports /root/reference through oracle/ref_shims.py, loads the seeded
+synthetic state dicts of seed_amd/weights.py into the reference modules (which also proves the
+state-dict key names/shapes match the reference's), runs them on CPU in fp32 and in bf16, and stores
+inputs' seeds + outputs.  The committed vectors are what pins oracle/seed_oracle.py on the GPU box,
+where /root/reference does not exist.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shims  # noqa: E402
+from seed_amd import config as C  # noqa: E402
+from seed_amd.weights import make_tokenizer_state_dict, make_llama_state_dict, calibrate_codebook  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_tokenizer_weights(mods, sd):
+    ve = {k[len("visual_encoder."):]: v for k, v in sd.items() if k.startswith("visual_encoder.")}
+    missing, unexpected = mods.visual_encoder.load_state_dict(ve, strict=True)
+    mods.ln_vision.load_state_dict({"weight": sd["ln_vision.weight"], "bias": sd["ln_vision.bias"]}, strict=True)
+    qf = {k[len("Qformer."):]: v for k, v in sd.items() if k.startswith("Qformer.")}
+    res = mods.Qformer.load_state_dict(qf, strict=False)
+    # every key we generate must exist in the reference module; the reference may hold extras
+    # (embeddings.position_ids buffer) that the encode path never reads
+    assert not res.unexpected_keys, res.unexpected_keys
+    leftover = [k for k in res.missing_keys if "position_ids" not in k]
+    assert not leftover, leftover
+    mods.encode_task_layer.load_state_dict(
+        {k[len("encode_task_layer."):]: v for k, v in sd.items() if k.startswith("encode_task_layer.")}, strict=True)
+    mods.quantize.embedding.weight.data.copy_(sd["quantize.embedding.weight"])
+
+
+def tokenizer_golden(name, cfg, batch, seed_w, seed_x, ref):
+    torch.manual_seed(0)
+    sd = make_tokenizer_state_dict(cfg, seed=seed_w, ln_jitter=0.05)
+    gen = torch.Generator().manual_seed(seed_x)
+    image = torch.randn(batch, 3, cfg.img_size, cfg.img_size, generator=gen)
+    mods = ref_shims.build_reference_tokenizer_modules(ref, cfg)
+    load_tokenizer_weights(mods, sd)
+    qt = sd["query_tokens"].clone()
+    # pass 1 (reference init codebook) only to obtain z; then a codebook with realistic margins
+    _, taps = ref_shims.reference_get_codebook_indices(mods, qt, image)
+    cb = calibrate_codebook(taps["z"], cfg.n_embed, seed=7)
+    sd["quantize.embedding.weight"] = cb
+    mods.quantize.embedding.weight.data.copy_(cb)
+    ids32, taps32 = ref_shims.reference_get_codebook_indices(mods, qt, image)
+
+    # native bf16 run of the same reference modules (CPU: maybe_autocast is a nullcontext, every op in bf16)
+    for m in (mods.visual_encoder, mods.Qformer, mods.quantize, mods.encode_task_layer):
+        m.bfloat16()
+    # blip2.LayerNorm feeds fp32 activations into F.layer_norm (blip2.py:183); on CPU that needs fp32
+    # parameters (GPU autocast upcasts them), so hold the bf16-rounded values in fp32.
+    for prm in mods.ln_vision.parameters():
+        prm.data = prm.data.bfloat16().float()
+    try:
+        ids16, taps16 = ref_shims.reference_get_codebook_indices(mods, qt.bfloat16(), image.bfloat16())
+        have16 = True
+    except Exception as e:  # pragma: no cover
+        print("bf16 reference run failed:", e)
+        have16 = False
+
+    out = dict(cfg=np.array(repr(cfg.to_dict())), seed_w=seed_w, seed_x=seed_x, batch=batch, ln_jitter=0.05,
+               codebook=cb.numpy(), image_sum=np.float64(image.double().sum().item()),
+               ids_fp32=ids32.numpy(), z_fp32=taps32["z"].numpy(), qformer_out_fp32=taps32["qformer_out"].numpy(),
+               image_embeds_fp32_slice=taps32["image_embeds"][:, :8, :64].numpy(),
+               image_embeds_fp32_absmean=np.float64(taps32["image_embeds"].abs().mean().item()))
+    if have16:
+        out.update(ids_bf16=ids16.numpy(), z_bf16=taps16["z"].float().numpy(),
+                   qformer_out_bf16=taps16["qformer_out"].float().numpy(),
+                   image_embeds_bf16_slice=taps16["image_embeds"][:, :8, :64].float().numpy())
+    np.savez_compressed(os.path.join(GOLDEN, f"tokenizer_{name}.npz"), **out)
+    print(name, "ids[0,:8] fp32", ids32[0, :8].tolist(), "bf16", ids16[0, :8].tolist() if have16 else None,
+          "agree", (ids32 == ids16).float().mean().item() if have16 else None)
+
+
+def vq_golden(ref):
+    """VectorQuantizer2 alone on the reference module: z, codebook -> ids (fp32 and bf16)."""
+    gen = torch.Generator().manual_seed(11)
+    vq = ref.quantizer.VectorQuantizer2(8192, 32, beta=0.25)
+    cb = torch.randn(8192, 32, generator=gen) * 0.3
+    z = cb[torch.randint(0, 8192, (4, 32), generator=gen)] + torch.randn(4, 32, 32, generator=gen) * 0.05
+    # force exact ties: duplicate code rows (first index must win) and a z that sits exactly on a code
+    cb[4001] = cb[17]
+    cb[7000] = cb[17]
+    z[0, 0] = cb[17]
+    z[0, 1] = cb[4001]
+    vq.embedding.weight.data.copy_(cb)
+    with torch.no_grad():
+        _, _, ids32 = vq(z)
+        vq.bfloat16()
+        _, _, ids16 = vq(z.bfloat16())
+    np.savez_compressed(os.path.join(GOLDEN, "vq_reference.npz"), z=z.numpy(), codebook=cb.numpy(),
+                        ids_fp32=ids32.reshape(4, 32).numpy(), ids_bf16=ids16.reshape(4, 32).numpy())
+    print("vq golden ids", ids32[:4].tolist(), ids16[:4].tolist())
+
+
+def llama_golden(ref):
+    cfg = C.LLAMA_TINY
+    from transformers.models.llama.configuration_llama import LlamaConfig as HFLlamaConfig
+    hf = HFLlamaConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.ffn,
+                       num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, rms_norm_eps=cfg.rms_eps,
+                       max_position_embeddings=cfg.max_pos, hidden_act="silu", pad_token_id=0)
+    model = ref.llama.LlamaForCausalLM(hf).eval()
+    sd = make_llama_state_dict(cfg, seed=3, norm_jitter=0.05)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all("rotary_emb" in k for k in res.missing_keys), res.missing_keys
+    gen = torch.Generator().manual_seed(5)
+    B, T, n_new = 2, 12, 4
+    ids = torch.randint(3, cfg.vocab, (B, T), generator=gen)
+    outs = {}
+    for tag, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        model.to(dt)
+        with torch.no_grad():
+            o = model(input_ids=ids, use_cache=True)
+            logits = [o.logits]
+            past = o.past_key_values
+            tok = o.logits[:, -1].float().argmax(-1, keepdim=True)
+            toks = [tok]
+            for _ in range(n_new - 1):
+                o = model(input_ids=tok, past_key_values=past, use_cache=True)
+                past = o.past_key_values
+                logits.append(o.logits)
+                tok = o.logits[:, -1].float().argmax(-1, keepdim=True)
+                toks.append(tok)
+        outs[f"prefill_logits_{tag}"] = logits[0].float().numpy()
+        outs[f"decode_logits_{tag}"] = torch.cat(logits[1:], dim=1).float().numpy()
+        outs[f"tokens_{tag}"] = torch.cat(toks, dim=1).numpy()
+        outs[f"k_cache0_{tag}"] = past[0][0].float().numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "llama_tiny.npz"), input_ids=ids.numpy(), seed_w=3, norm_jitter=0.05,
+                        n_new=n_new, **outs)
+    print("llama golden tokens", outs["tokens_fp32"].tolist(), outs["tokens_bf16"].tolist())
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    ref = ref_shims.load_reference_modules()
+    vq_golden(ref)
+    tokenizer_golden("tiny", C.TINY, 3, 0, 1234, ref)
+    tokenizer_golden("mid", C.MID, 2, 1, 4321, ref)
+    llama_golden(ref)
+
+
+if __name__ == "__main__":
+    main()
