@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native SEED tokenize-and-generate hot path (driver contract: see the task brief).
+
+    python bench.py                                   # 1 GPU, default K/W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the tokenize hot path over one batch of synthetic 224x224 images per GPU
+(BASELINE.json configs[1]: SEED-2 tokenize, batch 256 per GPU, bf16): ``encode_image`` = EVA-ViT-g/14 ->
+ln_vision -> causal Q-Former -> task MLP -> 8192-way VQ argmin, all inside ``seedmi_tokenize`` (hand-written
+HIP behind the C ABI), followed at N > 1 by the RCCL all-gather of the int64 [B,32] token ids (the path's only
+exchange step).  Images are resident in HBM before the timed region; weights are seeded
+random-init tensors of the exact architecture (no checkpoints offline).
+
+The JSON line also carries
+  roofline      the dominant kernel (ViT QKV GEMM, M=B*257, K=1408, N=4224) timed live with HIP events
+  cpu_baseline  the CPU oracle (oracle/seed_oracle.py, a port of the reference's modules) timed on this host
+  extra         whole-path MFMA fraction, SEED-LLaMA-8B greedy decode tokens/s (B=32) and its HBM roofline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--no-llama", action="store_true", help="skip the SEED-LLaMA-8B decode leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--decode-batch", type=int, default=32)
+    ap.add_argument("--decode-new", type=int, default=128)
+    return ap.parse_args()
+
+
+def time_kernel_events(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    beg = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    end = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    for i in range(iters):
+        beg[i].record()
+        fn()
+        end[i].record()
+    torch.cuda.synchronize()
+    ms = sorted(b.elapsed_time(e) for b, e in zip(beg, end))
+    return sum(ms) / len(ms), ms[len(ms) // 2]
+
+
+def qkv_gemm_roofline(batch):
+    """ViT QKV GEMM at this batch through the C ABI on torch's current stream, timed with HIP events."""
+    from seed_amd import lib as L
+    lib = L.load()
+    M, K, N = batch * 257, 1408, 4224
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.02).bfloat16()
+    bias = torch.zeros(N, device="cuda").bfloat16()
+    Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+
+    def run():
+        L.check(lib.seedmi_gemm_bf16(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(Cc), N,
+                                     0, 0, L.stream_ptr()), "gemm")
+    avg_ms, med_ms = time_kernel_events(run, 20)
+    flops = 2.0 * M * N * K
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm128_kernel<BIAS> (ViT QKV: M=%d K=%d N=%d)" % (M, K, N),
+            "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "flops_per_launch": flops, "avg_launch_ms": round(avg_ms, 4), "median_launch_ms": round(med_ms, 4)}
+
+
+def cpu_baseline(n_images):
+    """The oracle (CPU port of the reference modules, fp32, all host cores) on a bounded sample of the workload."""
+    from oracle import seed_oracle as O
+    from seed_amd import config as C
+    from seed_amd.weights import make_tokenizer_state_dict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = make_tokenizer_state_dict(C.SEED2, seed=0)
+    img = torch.randn(n_images, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    O.get_codebook_indices(sd, img[:1], C.SEED2, "fp32")           # warm-up (thread pool, allocator)
+    t0 = time.time()
+    O.get_codebook_indices(sd, img, C.SEED2, "fp32")
+    dt = time.time() - t0
+    return {"value": round(n_images / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n_images} images (one batch) of the same synthetic 224x224 workload, fp32 oracle, "
+                      f"torch CPU with {cores} threads, {dt:.1f} s"}
+
+
+def llama_decode_leg(B, n_new):
+    """SEED-LLaMA-8B (Vicuna-7B body, vocab 40194): image -> 32 tokens -> greedy decode, batch B, bf16."""
+    from seed_amd import config as C
+    from seed_amd.llama_engine import LlamaEngine
+    from seed_amd.weights import make_llama_state_dict
+    cfg = C.LLAMA_8B
+    sd = make_llama_state_dict(cfg, seed=0, device="cuda", dtype=torch.bfloat16)
+    T0 = 59                                                        # SURVEY.md section 8d config 3 prompt length
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=256)
+    del sd
+    g = torch.Generator(device="cuda").manual_seed(99)
+    prompt = torch.randint(3, 32000, (B, T0), device="cuda", generator=g)
+    prompt[:, 0] = 1
+    prompt[:, 10:42] = 32000 + torch.randint(0, 8192, (B, 32), device="cuda", generator=g)   # <img_XXXXX> x 32
+    eng.greedy_decode(prompt, 4)                                   # warm-up
+    torch.cuda.synchronize()
+    eng.reset()
+    t0 = time.time()
+    logits = eng.forward(prompt, last_only=True)
+    torch.cuda.synchronize()
+    t_prefill = time.time() - t0
+    tok = logits[:, 0].float().argmax(-1, keepdim=True)
+    t0 = time.time()
+    for _ in range(n_new - 1):
+        logits = eng.forward(tok, last_only=True)
+        tok = logits[:, 0].float().argmax(-1, keepdim=True)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    steps = n_new - 1
+    tok_s = B * steps / dt
+    ctx_mid = T0 + n_new // 2
+    bytes_step = cfg.linear_params() * 2 + B * ctx_mid * cfg.kv_bytes_per_token() + B * cfg.kv_bytes_per_token()
+    gbs = bytes_step / (dt / steps) / 1e9
+    return {"metric": "tokens/s SEED-LLaMA-8B greedy decode", "value": round(tok_s, 1), "batch": B, "new_tokens": n_new,
+            "ms_per_step": round(dt / steps * 1e3, 3), "prefill_ms": round(t_prefill * 1e3, 2), "prompt_len": T0,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_step": bytes_step}}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from seed_amd import config as C
+    from seed_amd.tokenizer_engine import TokenizerEngine
+    from seed_amd.weights import make_tokenizer_state_dict, calibrate_codebook
+    from seed_amd.dist import gather_token_ids
+
+    cfg = C.SEED2
+    B = args.batch
+    sd = make_tokenizer_state_dict(cfg, seed=0, device="cuda")
+    eng = TokenizerEngine(sd, cfg, device=f"cuda:{local}")
+    del sd
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    images = torch.randn(B, 3, 224, 224, device="cuda", generator=g).bfloat16()      # resident in HBM
+    taps = {}
+    eng.encode(images[:8], taps)
+    eng.set_codebook(calibrate_codebook(taps["z"].float().cpu(), cfg.n_embed, seed=7))
+    del taps
+
+    def step():
+        ids = eng.encode(images)
+        return gather_token_ids(ids, dist) if world > 1 else ids
+
+    for _ in range(args.warmup):
+        ids = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert tuple(ids.shape) == (world * B, 32) and int(ids.min()) >= 0 and int(ids.max()) < 8192
+
+    if rank == 0:
+        img_s = world * B * args.steps / dt
+        out = {
+            "metric": "images/s SEED-2 tokenize", "value": round(img_s, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SEED-2 tokenize (EVA-ViT-g/14 + causal Q-Former + 8192x32 VQ), 224x224, "
+                                   f"batch {B} per GPU, bf16; ids all-gathered over RCCL at N>1",
+                       "images_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
+                       "weights": "seeded random-init (reference initialisers)"},
+        }
+        flops_img = cfg.flops_per_image()
+        extra = {"gflop_per_image": round(flops_img / 1e9, 2),
+                 "path_mfma_frac": round(img_s / world * flops_img / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+        if world == 1:
+            out["roofline"] = qkv_gemm_roofline(B)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_images)
+        else:
+            out["roofline"] = None
+            out["cpu_baseline"] = None
+        del eng, images
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_llama:
+            try:
+                extra["llama_decode"] = llama_decode_leg(args.decode_batch, args.decode_new)
+            except Exception as e:  # the tokenize line must survive a failure of the secondary leg
+                extra["llama_decode"] = {"error": repr(e)[:300]}
+        out["extra"] = extra
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,190 @@
+/*
+ * seedmi — C ABI of the MI355X-native SEED tokenize-and-generate hot path (libseedmi.so, gfx950 only).
+ *
+ * This header is the drop-in boundary.  The reference (AILab-CVC/SEED @ 2024_10_08) is pure Python on
+ * PyTorch/xformers and has no FFI of its own; the entry points below are what a ctypes binding placed behind
+ *   models/seed_llama_tokenizer.py:75-90,185-202        (ImageTokenizer.encode / SeedLlamaTokenizer.encode_image)
+ *   models/seed_qformer/qformer_quantizer.py:288-307    (Blip2QformerQuantizer.get_codebook_indices)
+ *   models/llama_xformer.py:661-743                     (LlamaForCausalLM.forward)
+ * binds (see INTEGRATION.md for the stub).  Each kernel-level function cites the reference lines it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in signatures (`stream` is a hipStream_t passed
+ *     as void*; NULL = the null stream).
+ *   - every pointer is a DEVICE pointer owned by the caller; bf16 tensors are raw uint16 storage, row-major with an
+ *     explicit leading dimension in elements.  Pointers must be 16-byte aligned, leading dimensions multiples of 8.
+ *   - every call is asynchronous and stream-ordered; nothing is allocated or freed inside the library; scratch
+ *     memory is sized with *_workspace_bytes() and passed in.
+ *   - return value: 0 (SEEDMI_OK) or a negative SEEDMI_E_* code; seedmi_last_error() returns a thread-local
+ *     description of the last failure.  Errors correspond to the reference's Python asserts / ValueErrors
+ *     (seed_llama_tokenizer.py:192, eva_vit.py:227-228, llama_xformer.py:515-522).
+ *   - thread safety: calls on distinct streams with distinct workspaces may run concurrently; weight structs are
+ *     read-only.
+ */
+#ifndef SEEDMI_H
+#define SEEDMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEEDMI_OK 0
+#define SEEDMI_E_SHAPE (-1)
+#define SEEDMI_E_DTYPE (-2)
+#define SEEDMI_E_ALIGN (-3)
+#define SEEDMI_E_ARCH (-4)
+#define SEEDMI_E_HIP (-5)
+
+#define SEEDMI_ABI_VERSION 1
+
+int seedmi_version(void);
+const char* seedmi_last_error(void);
+/* 0 if the current device is a gfx950 (MI355X); SEEDMI_E_ARCH otherwise. */
+int seedmi_check_device(void);
+
+/* ---- GEMM epilogues ------------------------------------------------------------------------------------------ */
+#define SEEDMI_EPI_NONE 0          /* C = A W^T                                                                   */
+#define SEEDMI_EPI_BIAS 1          /* nn.Linear                                                                   */
+#define SEEDMI_EPI_BIAS_GELU 2     /* eva_vit.py:60-61, qformer_causual.py:321-322 (exact-erf GELU of the half fc1) */
+#define SEEDMI_EPI_BIAS_RESIDUAL 3 /* eva_vit.py:201-202, qformer_causual.py:252-254, llama_xformer.py:316,322     */
+#define SEEDMI_EPI_BIAS_TANH 4     /* qformer_quantizer.py:219-221                                                */
+#define SEEDMI_EPI_SWIGLU 5        /* llama_xformer.py:186 on row-interleaved gate/up weights; C is [M, N/2]        */
+#define SEEDMI_EPI_PATCH_EMBED 6   /* eva_vit.py:229 + 373-377: conv bias + pos_embed, output rows skip one cls row */
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]);  bf16 in/out, fp32 MFMA accumulation.  K % 64 == 0.
+ * residual/ldr: used by BIAS_RESIDUAL (same row as C) and PATCH_EMBED (pos_embed, row = m % row_group + row_extra;
+ * C row = m + (m / row_group + 1) * row_extra).  row_group/row_extra are ignored by the other epilogues. */
+int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
+                     const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group, int row_extra,
+                     void* stream);
+
+/* nn.LayerNorm with fp32 statistics (eva_vit.py:199-202, blip2.py:179-184, qformer_causual.py:96,254,336). */
+int seedmi_layernorm_bf16(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* out, int ldo,
+                          int rows, int cols, void* stream);
+/* LlamaRMSNorm.forward (llama_xformer.py:105-113). */
+int seedmi_rmsnorm_bf16(const void* x, int ldx, const void* gamma, float eps, void* out, int ldo, int rows, int cols,
+                        void* stream);
+/* PatchEmbed unfold (eva_vit.py:222-229): img [B,chans,hw,hw] (fp32 or bf16) -> col [B*(hw/patch)^2, kpad] bf16,
+ * k = (c, kh, kw), zero padded to kpad. */
+int seedmi_im2col_patch(const void* img, int img_is_fp32, void* col, int batch, int chans, int hw, int patch, int kpad,
+                        void* stream);
+/* dst[(g*group_rows + r0 + i), :cols] = src[i, :cols]  (cls rows: eva_vit.py:373-377; query expand: qformer_quantizer.py:293) */
+int seedmi_fill_rows(void* dst, int ld, int group_rows, int r0, int ngroups, const void* src, int lds, int nsrc,
+                     int cols, void* stream);
+/* softmax(Q K^T * scale [causal]) V for <= 288 keys; Q/K/V/O are [batch*n, ld] with head h in columns [h*hd,(h+1)*hd).
+ * eva_vit.py:139-156, qformer_causual.py:189-236.  round_scores=1 rounds S to bf16 before the softmax like the
+ * reference's half matmul output.  head_dim in {64, 88}. */
+int seedmi_attention_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                          int batch, int heads, int head_dim, int nq, int nk, float scale, int causal, int round_scores,
+                          void* stream);
+/* ||e||^2 of every codebook row with the reference's bf16 rounding points (qformer_quantizer.py:95). */
+int seedmi_vq_code_sqnorm(const void* codebook, void* ee_f32, int n_embed, int dim, void* stream);
+/* VectorQuantizer2 nearest neighbour (qformer_quantizer.py:94-98): ids[r] = argmin_n d(z_r, e_n), first index on ties,
+ * int64 output.  dim must be 32. */
+int seedmi_vq_argmin_bf16(const void* z, int ldz, const void* codebook, const void* ee_f32, void* ids_i64, int rows,
+                          int n_embed, int dim, void* stream);
+
+/* ---- LLaMA pieces ---------------------------------------------------------------------------------------------- */
+/* nn.Embedding gather (llama_xformer.py:544): out[i,:] = table[ids[i],:]. */
+int seedmi_embed_rows(const void* ids_i64, const void* table, int ldt, void* out, int ldo, int n, int cols, int vocab,
+                      void* stream);
+/* apply_rotary_pos_emb + KV append (llama_xformer.py:160-168,234-239): qkv [B*T, 3*H*hd] -> q_out [B*T, H*hd],
+ * caches [B][H][tmax][hd] written at positions past_len..past_len+T-1.  cos/sin: [max_pos, hd] bf16 tables. */
+int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t, const void* sin_t,
+                          void* q_out, int ldq, void* k_cache, void* v_cache, int B, int T, int H, int hd, int tmax,
+                          int past_len, void* stream);
+/* xformers.ops.memory_efficient_attention semantics (llama_xformer.py:244-256), head_dim 128:
+ * q [B*T, H*hd]; caches [B][H][tmax][hd] holding kv_len = past_len + T keys; causal (top-left aligned on the
+ * last T positions) when T > 1. */
+int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k_cache, const void* v_cache, void* out, int ldo,
+                                int B, int T, int H, int hd, int tmax, int past_len, float scale, void* stream);
+/* Skinny GEMM for decode (M <= 64): same contract as seedmi_gemm_bf16 restricted to NONE/BIAS_RESIDUAL/SWIGLU. */
+int seedmi_gemm_skinny_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* residual,
+                            int ldr, int epilogue, void* C, int ldc, void* stream);
+
+/* ---- path level: SEED-2 tokenizer ------------------------------------------------------------------------------ */
+typedef struct {
+    const void *ln1_w, *ln1_b;      /* blocks.N.norm1                                   */
+    const void *qkv_w, *qkv_b;      /* attn.qkv.weight [3D,D]; bias = cat(q_bias,0,v_bias) */
+    const void *proj_w, *proj_b;    /* attn.proj                                        */
+    const void *ln2_w, *ln2_b;      /* norm2                                            */
+    const void *fc1_w, *fc1_b;      /* mlp.fc1 [F,D]                                    */
+    const void *fc2_w, *fc2_b;      /* mlp.fc2 [D,F]                                    */
+} seedmi_vit_layer_t;
+
+typedef struct {
+    const void *qkv_w, *qkv_b;      /* attention.self.{query,key,value} stacked [3Q,Q]  */
+    const void *ao_w, *ao_b, *ao_ln_w, *ao_ln_b;          /* attention.output            */
+    int has_cross;
+    const void *cq_w, *cq_b;        /* crossattention.self.query [Q,Q]                  */
+    const void *ckv_w, *ckv_b;      /* crossattention.self.{key,value} stacked [2Q,D]   */
+    const void *co_w, *co_b, *co_ln_w, *co_ln_b;          /* crossattention.output       */
+    const void *ffn_w1, *ffn_b1;    /* intermediate_query.dense [FF,Q]                  */
+    const void *ffn_w2, *ffn_b2, *ffn_ln_w, *ffn_ln_b;    /* output_query                */
+} seedmi_qf_layer_t;
+
+typedef struct {
+    int img_size, patch, vit_dim, vit_depth, vit_heads, vit_ffn;
+    int qf_dim, qf_layers, qf_heads, qf_ffn, n_query, n_embed, code_dim;
+    int kpad;                        /* patch-embed K (3*patch*patch) zero padded to a multiple of 64 */
+    const void *patch_w, *patch_b;   /* [D, kpad], [D]                                    */
+    const void* pos_embed;           /* [n_tokens, D]                                     */
+    const void* cls_pos0;            /* [D] = half(cls_token + pos_embed[0])              */
+    const seedmi_vit_layer_t* vit;   /* host array [vit_depth]                            */
+    const void *ln_vision_w, *ln_vision_b;
+    const void* query_ln;            /* [n_query, Q] = embeddings.LayerNorm(query_tokens), input independent */
+    const seedmi_qf_layer_t* qf;     /* host array [qf_layers]                            */
+    const void *head_w0, *head_b0;   /* encode_task_layer.0 [Q,Q]                         */
+    const void *head_w1, *head_b1;   /* encode_task_layer.2 [code_dim,Q]                  */
+    const void* codebook;            /* quantize.embedding.weight [n_embed, code_dim]     */
+    const void* code_sqnorm;         /* fp32 [n_embed] from seedmi_vq_code_sqnorm         */
+} seedmi_tokenizer_weights_t;
+
+typedef struct {                     /* optional device outputs for parity checks; any may be NULL */
+    void* image_embeds;              /* [B*n_tokens, D] bf16  (ln_vision output)          */
+    void* qformer_out;               /* [B*n_query, Q] bf16                               */
+    void* z;                         /* [B*n_query, code_dim] bf16                        */
+} seedmi_tokenizer_taps_t;
+
+size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int batch);
+/* Blip2QformerQuantizer.get_codebook_indices + ImageTokenizer.encode (qformer_quantizer.py:288-307,
+ * seed_llama_tokenizer.py:75-90): images [B,3,S,S] (fp32 or bf16) -> ids int64 [B, n_query] in [0, n_embed). */
+int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch, void* ids_i64,
+                    const seedmi_tokenizer_taps_t* taps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- path level: LLaMA forward --------------------------------------------------------------------------------- */
+typedef struct {
+    const void *ln1_w;               /* input_layernorm                                   */
+    const void *qkv_w;               /* {q,k,v}_proj stacked [3h,h]                       */
+    const void *o_w;                 /* o_proj [h,h]                                      */
+    const void *ln2_w;               /* post_attention_layernorm                          */
+    const void *gate_up_w;           /* gate_proj/up_proj row-interleaved [2F,h]          */
+    const void *down_w;              /* down_proj [h,F]                                   */
+    void *k_cache, *v_cache;         /* [B][H][tmax][hd] bf16, caller owned               */
+} seedmi_llama_layer_t;
+
+typedef struct {
+    int hidden, layers, heads, ffn, vocab, vocab_pad, max_pos, tmax, batch_cap;
+    float rms_eps;
+    const void* embed;               /* embed_tokens [vocab, h]                           */
+    const seedmi_llama_layer_t* layer; /* host array [layers]                             */
+    const void* norm_w;              /* model.norm                                        */
+    const void* lm_head;             /* [vocab_pad, h] (rows >= vocab zero)               */
+    const void *cos_t, *sin_t;       /* [max_pos, hd] bf16                                */
+} seedmi_llama_weights_t;
+
+size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, int batch, int T);
+/* LlamaForCausalLM.forward, eval, use_cache (llama_xformer.py:661-743): ids/pos int64 [B,T]; appends to the static
+ * KV cache at past_len; logits bf16 [B*T_out, ldl] where T_out = T (all positions, reference behaviour) or 1
+ * (last position only, decode fast path) depending on last_only. */
+int seedmi_llama_forward(const seedmi_llama_weights_t* w, const void* ids_i64, const void* pos_i64, int batch, int T,
+                         int past_len, int last_only, void* logits, int ldl, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEDMI_H */

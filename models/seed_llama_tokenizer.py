@@ -1,0 +1,153 @@
+"""Drop-in for the reference's models/seed_llama_tokenizer.py: same classes, signatures and error behaviour, with
+``ImageTokenizer.encode`` running on the MI355X-native path.
+
+Reference lines mirrored: ImageTokenizer.__init__ 24-70, .encode 75-90, .decode 92-113; SeedLlamaTokenizer.__init__
+116-142, load_image_tokenizer 144-157, image_tokenizer 159-174, num_image_tokens 176-178, to 180-183,
+encode_image 185-202, decode_image 204-213.
+"""
+import os
+from typing import Any, Dict, Optional
+
+import torch
+from transformers import LlamaTokenizer
+
+from seed_amd.config import SEED2
+
+WEIGHTS_NAME = 'seed_quantizer.pt'
+DIFFUSION_NAME = 'diffusion_model'
+
+
+def _make_processor(image_size):
+    """Resize((S,S), bicubic) -> ToTensor -> Normalize(CLIP mean/std)  (seed_llama_tokenizer.py:50-56)."""
+    try:
+        from torchvision import transforms
+        return transforms.Compose([
+            transforms.Resize((image_size, image_size), interpolation=3),
+            transforms.ToTensor(),
+            transforms.Normalize(mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)),
+        ])
+    except ImportError:
+        from .transforms import _Compose, _pil_resize, _to_tensor, _normalize, CLIP_MEAN, CLIP_STD
+        return _Compose([_pil_resize((image_size, image_size), interpolation=3), _to_tensor, _normalize(CLIP_MEAN, CLIP_STD)])
+
+
+class ImageTokenizer:
+    def __init__(self, model_path, diffusion_model_path=None, load_diffusion=False, image_size=224, device='cuda',
+                 fp16=True, **kwargs):
+        from .seed_qformer.qformer_quantizer import Blip2QformerQuantizer
+        model = Blip2QformerQuantizer.from_pretrained(pretrained_model_path=model_path, device=device, **kwargs).eval()
+        if diffusion_model_path is not None and load_diffusion:
+            raise NotImplementedError(
+                "load_diffusion=True: the unCLIP de-tokenizer (models/pipeline_stable_unclip_img2img.py) is outside the "
+                "accelerated hot path; construct with load_diffusion=False")
+        self.diffusion_model = None
+        model = model.to(device)
+        if fp16:
+            model = model.half()
+        self.model = model
+        self.processor = _make_processor(image_size)
+        self.device = device
+        self.fp16 = fp16
+
+    def __len__(self):
+        return self.model.n_embed
+
+    def to(self, device=None, **kwargs):
+        self.device = device
+        self.model.to(device)
+        return self
+
+    def encode(self, image_torch):
+        '''Convert a batch of img to code
+        Args:
+            img: [b, c, h, w]   (the caller places it on the device, as in the reference)
+        '''
+        if len(image_torch.shape) == 3:
+            image_torch = image_torch.unsqueeze(0)
+        img = image_torch
+        with torch.no_grad():
+            id, _ = self.model.get_codebook_indices(img)
+        return id.view(img.shape[0], -1)
+
+    def decode(self, indices, negative_indices=None, guidance_scale=10, num_inference_steps=20):
+        raise NotImplementedError("image de-tokenization (unCLIP) is outside the accelerated hot path")
+
+
+class SeedLlamaTokenizer(LlamaTokenizer):
+    def __init__(self,
+                 vocab_file=None,
+                 unk_token="<unk>",
+                 bos_token="<s>",
+                 eos_token="</s>",
+                 pad_token=None,
+                 sp_model_kwargs: Optional[Dict[str, Any]] = None,
+                 add_bos_token=True,
+                 add_eos_token=False,
+                 clean_up_tokenization_spaces=False,
+                 device='cuda',
+                 fp16=True,
+                 load_diffusion=False,
+                 encoder_url=None,
+                 diffusion_path=None,
+                 image_tokenizer_kwargs: Optional[Dict[str, Any]] = None,
+                 **kwargs):
+        # transformers >= 5 renamed the first argument (`vocab`) and dropped sp_model_kwargs/add_*_token positionals
+        kwargs.pop("vocab", None) if vocab_file is not None else None
+        super().__init__(vocab=vocab_file if vocab_file is not None else kwargs.pop("vocab", None),
+                         unk_token=unk_token, bos_token=bos_token, eos_token=eos_token,
+                         clean_up_tokenization_spaces=clean_up_tokenization_spaces, **kwargs)
+        self.device = device
+        self.fp16 = fp16
+        self.pad_token = self.unk_token
+        self.load_diffusion = load_diffusion
+        self.encoder_url = encoder_url
+        self.diffusion_path = diffusion_path
+        self._image_tokenizer_kwargs = image_tokenizer_kwargs or {}
+        if self.encoder_url is not None or (getattr(self, 'name_or_path', None) and os.path.exists(
+                os.path.join(self.name_or_path, WEIGHTS_NAME))):
+            self.load_image_tokenizer()
+
+    def _model_path(self):
+        if self.encoder_url is not None:
+            return self.encoder_url
+        assert hasattr(self, 'name_or_path') and os.path.exists(self.name_or_path)
+        return os.path.join(self.name_or_path, WEIGHTS_NAME)
+
+    def load_image_tokenizer(self):
+        if not hasattr(self, '_image_tokenizer'):
+            self._image_tokenizer = ImageTokenizer(model_path=self._model_path(),
+                                                   diffusion_model_path=self.diffusion_path,
+                                                   load_diffusion=self.load_diffusion,
+                                                   device=self.device,
+                                                   fp16=self.fp16,
+                                                   **self._image_tokenizer_kwargs)
+
+    @property
+    def image_tokenizer(self):
+        self.load_image_tokenizer()
+        return self._image_tokenizer
+
+    @property
+    def num_image_tokens(self):
+        return 8192
+
+    def to(self, device):
+        self.device = device
+        if hasattr(self, '_image_tokenizer'):
+            self._image_tokenizer.to(device=device)
+
+    def encode_image(self, image_path=None, image_pil=None, image_torch=None, image_size: int = 224):
+        assert (image_path is None) + (image_pil is None) + (image_torch is None) == 2
+        if image_path is not None:
+            from PIL import Image
+            image_pil = Image.open(image_path).convert('RGB')
+        if image_pil is not None:
+            image_torch = self.image_tokenizer.processor(image_pil)
+            image_torch = image_torch.to(self.device)
+        return self.image_tokenizer.encode(image_torch)
+
+    def decode_image(self, indices, negative_indices=None, guidance_scale=10):
+        indices = indices.to(self.device)
+        if negative_indices is not None:
+            negative_indices = negative_indices.to(self.device)
+        return self.image_tokenizer.decode(indices, negative_indices=negative_indices, guidance_scale=guidance_scale)

@@ -1,0 +1,85 @@
+"""Drop-in for the reference's models/seed_qformer/qformer_quantizer.py (encode side), backed by libseedmi.so.
+
+``Blip2QformerQuantizer`` keeps the reference's construction and call surface
+(``from_pretrained(pretrained_model_path, **kwargs)``, ``get_codebook_indices(image) -> (embed_ind, query_output_up)``,
+``.to()/.half()/.eval()``, attributes ``n_embed``, ``visual_encoder``) — qformer_quantizer.py:143-375 — but holds
+no torch modules: the state dict is repacked once into the HIP engine (seed_amd/tokenizer_engine.py) and
+``get_codebook_indices`` is a single C-ABI call (seedmi_tokenize).  The de-tokenizer half
+(``get_codebook_entry`` -> unCLIP, qformer_quantizer.py:309-338) is outside this round's scope and
+raises.
+"""
+import torch
+
+from seed_amd.config import TokenizerConfig, SEED2
+from seed_amd.tokenizer_engine import TokenizerEngine
+
+
+class _DeviceHandle:
+    """Stands in for sub-modules that serving code moves between devices
+    (gradio_demo/seed_llama_flask.py:72-80 calls ``model.visual_encoder.to(...)``): weights stay resident in HBM
+    (2.18 GB of 288 GB), so offload requests are accepted and ignored."""
+
+    def to(self, *a, **k):
+        return self
+
+    def cpu(self):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+
+class Blip2QformerQuantizer:
+    def __init__(self, state_dict=None, cfg: TokenizerConfig = SEED2, device="cuda", **kwargs):
+        self.cfg = cfg
+        self.n_embed = cfg.n_embed
+        self.codebook_embed_dim = cfg.code_dim
+        self.visual_encoder = _DeviceHandle()
+        self._state_dict = state_dict
+        self._device = torch.device(device) if device is not None else None
+        self._engine = None
+
+    # -- reference constructor path (qformer_quantizer.py:340-375)
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, **kwargs):
+        cfg = kwargs.pop("cfg", SEED2)
+        device = kwargs.pop("device", "cuda")
+        if isinstance(pretrained_model_path, dict):
+            ckpt = pretrained_model_path
+        elif str(pretrained_model_path).startswith("http"):
+            raise RuntimeError(f"offline: cannot download {pretrained_model_path}; pass a local seed_quantizer.pt")
+        else:
+            ckpt = torch.load(pretrained_model_path, map_location="cpu")
+        return cls(state_dict=ckpt, cfg=cfg, device=device)
+
+    # -- nn.Module-ish plumbing used by ImageTokenizer (seed_llama_tokenizer.py:38,48,58-59)
+    def eval(self):
+        return self
+
+    def half(self):
+        return self          # the MI355X path computes in bf16 with fp32 accumulation whichever half type is asked for
+
+    def to(self, device=None, *a, **k):
+        if device is not None and not isinstance(device, torch.dtype):
+            dev = torch.device(device)
+            if self._engine is not None and dev != self._engine.device:
+                self._engine = None
+            self._device = dev
+        return self
+
+    @property
+    def engine(self) -> TokenizerEngine:
+        if self._engine is None:
+            if self._state_dict is None:
+                raise RuntimeError("Blip2QformerQuantizer has no weights (use from_pretrained or pass state_dict)")
+            self._engine = TokenizerEngine(self._state_dict, self.cfg, device=self._device)   # raises without a GPU
+        return self._engine
+
+    def get_codebook_indices(self, image):
+        """qformer_quantizer.py:288-307.  Returns (embed_ind int64 [B,32], None): ``query_output_up`` feeds only the
+        de-tokenizer and is dead work for encode_image, so it is not computed."""
+        with torch.no_grad():
+            return self.engine.encode(image), None
+
+    def get_codebook_entry(self, indices):
+        raise NotImplementedError("de-tokenizer (codebook entry -> unCLIP embedding) is outside the accelerated hot path")

@@ -1,0 +1,64 @@
+"""Build libseedmi.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m seed_amd.build            # incremental
+    python -m seed_amd.build --force
+
+The .so stays inside the package directory (git-ignored, but it travels with gpurun snapshots) so the
+driver sees the native code that the tests load.  hipcc cross-compiles for gfx950 without a GPU.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libseedmi.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["capi.hip", "gemm_bf16.hip", "attn_fullrow.hip", "norm_misc.hip", "vq_argmin.hip", "tokenizer.hip", "llama.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _deps_mtime():
+    latest = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            if f.endswith((".h", ".hip")):
+                latest = max(latest, os.path.getmtime(os.path.join(root, f)))
+    return latest
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    srcp = os.path.join(CSRC, src)
+    hdr_m = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    hdr_m = max(hdr_m, os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "seedmi.h")))
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_m):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", srcp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj, True
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    objs = [o for o, _ in results]
+    if any(changed for _, changed in results) or not os.path.exists(LIB) or force:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[seed_amd.build] linked {LIB}")
+    elif verbose:
+        print(f"[seed_amd.build] {LIB} up to date")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

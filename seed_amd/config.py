@@ -81,7 +81,7 @@ SEED2 = TokenizerConfig()
 TINY = TokenizerConfig(img_size=56, patch=14, vit_dim=128, vit_depth=2, vit_heads=2, vit_mlp_ratio=4.0,
                        qf_dim=128, qf_layers=2, qf_heads=2, qf_ffn=256, n_query=32, n_embed=512, code_dim=32)
 # keeps the MFMA-hostile dims of the real model (hd = 88, 257 tokens, 64-wide Q-Former heads) at small depth
-MID = TokenizerConfig(img_size=224, patch=14, vit_dim=352, vit_depth=2, vit_heads=4, vit_mlp_ratio=4.0,
+MID = TokenizerConfig(img_size=224, patch=14, vit_dim=704, vit_depth=2, vit_heads=8, vit_mlp_ratio=4.0,
                       qf_dim=256, qf_layers=2, qf_heads=4, qf_ffn=512, n_query=32, n_embed=8192, code_dim=32)
 
 

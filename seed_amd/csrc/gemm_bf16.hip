@@ -1,0 +1,279 @@
+// bf16 GEMM with fused epilogues for gfx950:  C[M,N] = epi(A[M,K] * W[N,K]^T + bias)
+//
+// Replaces every nn.Linear / F.linear on the hot path (eva_vit.py:135,157,60,64;
+// qformer_causual.py:165-179,252,321,334; qformer_quantizer.py:219-223; llama_xformer.py:223-225,258,186,718)
+// and the patch-embed conv-as-GEMM (eva_vit.py:229).  A and W are both K-contiguous (activation rows,
+// nn.Linear weight rows), fp32 accumulation on the MFMA pipe, one rounding to bf16 after the bias
+// (what cuBLAS/oneDNN do for the reference), further roundings where the reference materialises
+// another half tensor (GELU output, residual sum, ...).
+//
+// Kernel "gemm128": 128x128x64 block tile, 4 waves (2x2), 64x64 per wave = 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16.  Operands are staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round
+// trip), double buffered, one barrier per K-tile.  LDS rows are 128 B; the 16-B chunk index is XOR-swizzled
+// so each ds_read_b128 lane group touches 16 distinct 16-B slots (the swizzle is applied on the per-lane
+// *global source* address and on the read address; the LDS image itself must stay lane-linear for LDS-DMA).
+// MFMA orientation is swapped (weights are the A operand) and the weight rows feeding one MFMA are
+// {16a + 4*ni + b}, so after the K loop every lane owns 16 *contiguous* output columns of 4 rows:
+// the epilogue issues 16-byte loads/stores only.
+//
+// Workgroups are remapped so that each XCD (private 4 MiB L2) walks a contiguous range of tiles in
+// grouped (8 m-tiles x all n-tiles) order.
+#include "common.h"
+#include "seedmi_internal.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;          // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A tile + W tile
+constexpr int GROUP_M = 8;
+
+struct GemmParams {
+    int M, N, K;
+    const bf16_t* A; int lda;
+    const bf16_t* W; int ldw;
+    const bf16_t* bias;
+    const bf16_t* R; int ldr;
+    bf16_t* C; int ldc;
+    int tiles_m, tiles_n;
+    int row_group, row_extra;   // patch-embed: out_row = m + (m / row_group) * row_extra + row_extra ; res_row = m % row_group + row_extra
+};
+
+SEEDMI_DEVINL int swzA(int row) { return (row >> 1) & 7; }
+SEEDMI_DEVINL int swzW(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+SEEDMI_DEVINL void glds16(const bf16_t* gptr, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, g = lane >> 4;
+
+    // ---- workgroup -> tile (XCD-contiguous, grouped order)
+    int tm, tn;
+    {
+        const int nt = p.tiles_m * p.tiles_n;
+        const int bid = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int gsize = GROUP_M * p.tiles_n;
+        const int gid = t / gsize;
+        const int first_m = gid * GROUP_M;
+        const int gm = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = t - gid * gsize;
+        tm = first_m + in_g % gm;
+        tn = in_g / gm;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses: wave w copies rows [32w, 32w+32) of both tiles, 4 LDS-DMA pieces of 8 rows each
+    int offA[4], offW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 32 * wave + 8 * j + (lane >> 3);
+        const int cs = lane & 7;                                  // chunk slot this lane fills in LDS
+        const int ra = min(m0 + row, p.M - 1);
+        const int rw = min(n0 + row, p.N - 1);
+        offA[j] = ra * p.lda + 8 * (cs ^ swzA(row));
+        offW[j] = rw * p.ldw + 8 * (cs ^ swzW(row));
+    }
+    // ---- fragment read addresses (byte offsets inside a stage), k-step 0; k-step 1 = ^64
+    int rdA[4], rdW[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ra = 64 * wm + 16 * t + li;                     // activation row feeding MFMA column li
+        rdA[t] = ra * 128 + ((g ^ swzA(ra)) << 4);
+        const int rw = 64 * wn + 16 * (li >> 2) + 4 * t + (li & 3);   // weight row feeding MFMA row li
+        rdW[t] = TILE_BYTES + rw * 128 + ((g ^ swzW(rw)) << 4);
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    auto stage = [&](int s, int kt) {
+        char* base = smem + s * STAGE_BYTES + wave * 4096;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(p.A + (size_t)(offA[j] + k0), base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(p.W + (size_t)(offW[j] + k0), base + TILE_BYTES + j * 1024);
+    };
+
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = *(const bf16x8*)(sb + (rdA[t] ^ (ks << 6)));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = *(const bf16x8*)(sb + (rdW[t] ^ (ks << 6)));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns rows m = m0+64wm+16mi+li (mi=0..3), columns nb..nb+15
+    const int nb = n0 + 64 * wn + 16 * g;
+    if (nb >= p.N) return;
+    const bool full = (nb + 16 <= p.N);
+    float bias[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bias[i] = 0.f;
+    if (EPI != EPI_NONE && p.bias) {
+        if (full) {
+            const uint4 b0 = *(const uint4*)(p.bias + nb);
+            const uint4 b1 = *(const uint4*)(p.bias + nb + 8);
+            const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { bias[2 * i] = lo_bf(bw[i]); bias[2 * i + 1] = hi_bf(bw[i]); }
+        } else {
+            for (int i = 0; i < 16; ++i) if (nb + i < p.N) bias[i] = bf2f(p.bias[nb + i]);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + 64 * wm + 16 * mi + li;
+        if (m >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[mi][ni][r] + bias[4 * ni + r];
+
+        int out_row = m;
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = gelu_erf(rbf(v[i]));      // GELU of the half fc1 output
+        } else if (EPI == EPI_BIAS_TANH) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = tanhf(rbf(v[i]));
+        } else if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_PATCH_EMBED) {
+            int res_row = m;
+            if (EPI == EPI_PATCH_EMBED) {
+                const int img = m / p.row_group;
+                res_row = m - img * p.row_group + p.row_extra;            // pos_embed row (skip cls)
+                out_row = m + (img + 1) * p.row_extra;                    // leave room for one cls row per image
+            }
+            const bf16_t* rp = p.R + (size_t)res_row * p.ldr + nb;
+            if (full) {
+                const uint4 r0 = *(const uint4*)rp;
+                const uint4 r1 = *(const uint4*)(rp + 8);
+                const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[2 * i] = rbf(v[2 * i]) + lo_bf(rw[i]);               // half GEMM output + half residual
+                    v[2 * i + 1] = rbf(v[2 * i + 1]) + hi_bf(rw[i]);
+                }
+            } else {
+                for (int i = 0; i < 16; ++i) if (nb + i < p.N) v[i] = rbf(v[i]) + bf2f(rp[i]);
+            }
+        }
+
+        if (EPI == EPI_SWIGLU) {
+            // interleaved rows: even = gate_proj, odd = up_proj  ->  out[m][n/2] = silu(gate) * up
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = rbf(silu(rbf(v[2 * i]))) * rbf(v[2 * i + 1]);
+            bf16_t* cp = p.C + (size_t)out_row * p.ldc + (nb >> 1);
+            if (full) {
+                uint4 s;
+                s.x = pack2bf(o[0], o[1]); s.y = pack2bf(o[2], o[3]); s.z = pack2bf(o[4], o[5]); s.w = pack2bf(o[6], o[7]);
+                *(uint4*)cp = s;
+            } else {
+                for (int i = 0; i < 8; ++i) if (nb + 2 * i + 1 < p.N) cp[i] = f2bf(o[i]);
+            }
+        } else {
+            bf16_t* cp = p.C + (size_t)out_row * p.ldc + nb;
+            if (full) {
+                uint4 s0, s1;
+                s0.x = pack2bf(v[0], v[1]); s0.y = pack2bf(v[2], v[3]); s0.z = pack2bf(v[4], v[5]); s0.w = pack2bf(v[6], v[7]);
+                s1.x = pack2bf(v[8], v[9]); s1.y = pack2bf(v[10], v[11]); s1.z = pack2bf(v[12], v[13]); s1.w = pack2bf(v[14], v[15]);
+                *(uint4*)cp = s0;
+                *(uint4*)(cp + 8) = s1;
+            } else {
+                for (int i = 0; i < 16; ++i) if (nb + i < p.N) cp[i] = f2bf(v[i]);
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm128(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        attr_set = true;
+    }
+    const int grid = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(gemm128_kernel<EPI>, dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, p);
+    return seedmi_check_launch("gemm128");
+}
+
+}  // namespace
+
+extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
+                                const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group,
+                                int row_extra, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) {
+        seedmi_set_error("seedmi_gemm_bf16: bad shape M=%d N=%d K=%d (K must be a positive multiple of %d)", M, N, K, BK);
+        return SEEDMI_E_SHAPE;
+    }
+    if ((lda % 8) || (ldw % 8) || (ldc % 8) || (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) ||
+        (bias && ((uintptr_t)bias & 15)) || (residual && (((uintptr_t)residual & 15) || (ldr % 8)))) {
+        seedmi_set_error("seedmi_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
+        return SEEDMI_E_ALIGN;
+    }
+    if ((epilogue == EPI_BIAS_RESIDUAL || epilogue == EPI_PATCH_EMBED) && !residual) {
+        seedmi_set_error("seedmi_gemm_bf16: residual epilogue without a residual pointer");
+        return SEEDMI_E_SHAPE;
+    }
+    if (epilogue == EPI_SWIGLU && (N % 2)) {
+        seedmi_set_error("seedmi_gemm_bf16: SWIGLU needs an even N (interleaved gate/up rows)");
+        return SEEDMI_E_SHAPE;
+    }
+    GemmParams p;
+    p.M = M; p.N = N; p.K = K;
+    p.A = (const bf16_t*)A; p.lda = lda;
+    p.W = (const bf16_t*)W; p.ldw = ldw;
+    p.bias = (const bf16_t*)bias;
+    p.R = (const bf16_t*)residual; p.ldr = ldr;
+    p.C = (bf16_t*)C; p.ldc = ldc;
+    p.tiles_m = (M + BM - 1) / BM;
+    p.tiles_n = (N + BN - 1) / BN;
+    p.row_group = row_group > 0 ? row_group : 1;
+    p.row_extra = row_extra;
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case EPI_NONE: return launch_gemm128<EPI_NONE>(p, s);
+        case EPI_BIAS: return launch_gemm128<EPI_BIAS>(p, s);
+        case EPI_BIAS_GELU: return launch_gemm128<EPI_BIAS_GELU>(p, s);
+        case EPI_BIAS_RESIDUAL: return launch_gemm128<EPI_BIAS_RESIDUAL>(p, s);
+        case EPI_BIAS_TANH: return launch_gemm128<EPI_BIAS_TANH>(p, s);
+        case EPI_SWIGLU: return launch_gemm128<EPI_SWIGLU>(p, s);
+        case EPI_PATCH_EMBED: return launch_gemm128<EPI_PATCH_EMBED>(p, s);
+        default:
+            seedmi_set_error("seedmi_gemm_bf16: unknown epilogue %d", epilogue);
+            return SEEDMI_E_SHAPE;
+    }
+}

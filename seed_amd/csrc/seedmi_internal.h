@@ -1,0 +1,14 @@
+// Internal declarations shared by the seedmi translation units (not part of the public C ABI).
+#pragma once
+#include <stdint.h>
+
+// epilogue selectors of seedmi_gemm_bf16 (mirrored in include/seedmi.h and seed_amd/lib.py)
+enum {
+    EPI_NONE = 0,           // C = A W^T
+    EPI_BIAS = 1,           // + bias                       (nn.Linear)
+    EPI_BIAS_GELU = 2,      // gelu_erf(half(. + bias))     (eva_vit.py:60-61, qformer_causual.py:321-322)
+    EPI_BIAS_RESIDUAL = 3,  // half(. + bias) + residual    (eva_vit.py:201-202, qformer_causual.py:252-254, llama_xformer.py:316,322)
+    EPI_BIAS_TANH = 4,      // tanh(half(. + bias))         (qformer_quantizer.py:219-221)
+    EPI_SWIGLU = 5,         // silu(gate) * up on interleaved rows (llama_xformer.py:186)
+    EPI_PATCH_EMBED = 6,    // conv bias + pos_embed, rows shifted past each image's cls slot (eva_vit.py:229,373-377)
+};

@@ -1,0 +1,148 @@
+// Path-level entry: SEED-2 image tokenizer forward (EVA-ViT-g -> ln_vision -> causal Q-Former -> task MLP -> VQ).
+//
+// Host-side orchestration of the kernel-level C ABI; mirrors, step for step,
+//   Blip2QformerQuantizer.get_codebook_indices   models/seed_qformer/qformer_quantizer.py:288-307
+//   VisionTransformer.forward_features            models/seed_qformer/eva_vit.py:369-385
+//   BertModel.forward / BertLayer.forward         models/seed_qformer/qformer_causual.py:769-931, 359-444
+// Everything is enqueued on one stream; no allocation, no host sync, so the call is hipGraph-capturable.
+#include "common.h"
+#include "../../include/seedmi.h"
+
+namespace {
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base((char*)p) {}
+    void* take(size_t bytes) {
+        void* r = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return r;
+    }
+};
+
+struct TokWs {
+    bf16_t *col, *x, *xn, *qkv, *h, *kv, *qx, *qa, *qt, *qqkv, *qh, *z;
+    size_t bytes;
+};
+
+TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
+    const int grid = w->img_size / w->patch;
+    const size_t P = (size_t)grid * grid, NT = P + 1;
+    const size_t M = (size_t)B * NT, Mq = (size_t)B * w->n_query;
+    const size_t D = w->vit_dim, F = w->vit_ffn, Q = w->qf_dim, FF = w->qf_ffn;
+    Carver c(ws);
+    TokWs t;
+    t.col = (bf16_t*)c.take((size_t)B * P * w->kpad * 2);
+    t.x = (bf16_t*)c.take(M * D * 2);
+    t.xn = (bf16_t*)c.take(M * D * 2);
+    t.qkv = (bf16_t*)c.take(M * 3 * D * 2);
+    t.h = (bf16_t*)c.take(M * F * 2);
+    t.kv = (bf16_t*)c.take(M * 2 * Q * 2);
+    t.qx = (bf16_t*)c.take(Mq * Q * 2);
+    t.qa = (bf16_t*)c.take(Mq * Q * 2);
+    t.qt = (bf16_t*)c.take(Mq * Q * 2);
+    t.qqkv = (bf16_t*)c.take(Mq * 3 * Q * 2);
+    t.qh = (bf16_t*)c.take(Mq * FF * 2);
+    t.z = (bf16_t*)c.take(Mq * 64 * 2);
+    t.bytes = c.off;
+    return t;
+}
+
+#define CK(call)                  \
+    do {                          \
+        const int rc_ = (call);   \
+        if (rc_ != SEEDMI_OK) return rc_; \
+    } while (0)
+
+}  // namespace
+
+extern "C" size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int batch) {
+    if (!w || batch <= 0) return 0;
+    return carve(w, batch, nullptr).bytes;
+}
+
+extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch,
+                               void* ids_i64, const seedmi_tokenizer_taps_t* taps, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!w || !images || !ids_i64 || batch <= 0) {
+        seedmi_set_error("seedmi_tokenize: null argument or batch=%d", batch);
+        return SEEDMI_E_SHAPE;
+    }
+    if (w->img_size % w->patch || w->vit_dim % w->vit_heads || w->qf_dim % w->qf_heads) {
+        seedmi_set_error("seedmi_tokenize: inconsistent dims (img %d / patch %d, D %d / heads %d, Q %d / heads %d)",
+                         w->img_size, w->patch, w->vit_dim, w->vit_heads, w->qf_dim, w->qf_heads);
+        return SEEDMI_E_SHAPE;
+    }
+    const TokWs t = carve(w, batch, workspace);
+    if (!workspace || workspace_bytes < t.bytes || ((uintptr_t)workspace & 255)) {
+        seedmi_set_error("seedmi_tokenize: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, t.bytes);
+        return SEEDMI_E_ALIGN;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int B = batch;
+    const int grid = w->img_size / w->patch;
+    const int P = grid * grid, NT = P + 1;
+    const int M = B * NT, Mq = B * w->n_query;
+    const int D = w->vit_dim, F = w->vit_ffn, H = w->vit_heads, hd = D / H;
+    const int Q = w->qf_dim, FF = w->qf_ffn, QH = w->qf_heads, qhd = Q / QH;
+
+    // ---- patch embed: unfold -> GEMM(+conv bias, +pos_embed, rows shifted past the cls slot); cls rows
+    CK(seedmi_im2col_patch(images, images_fp32, t.col, B, 3, w->img_size, w->patch, w->kpad, s));
+    CK(seedmi_gemm_bf16(B * P, D, w->kpad, t.col, w->kpad, w->patch_w, w->kpad, w->patch_b, w->pos_embed, D,
+                        SEEDMI_EPI_PATCH_EMBED, t.x, D, P, 1, s));
+    CK(seedmi_fill_rows(t.x, D, NT, 0, B, w->cls_pos0, D, 1, D, s));
+
+    // ---- 39 x Block (eva_vit.py:199-202)
+    const float vit_scale = 1.0f / sqrtf((float)hd);
+    for (int l = 0; l < w->vit_depth; ++l) {
+        const seedmi_vit_layer_t& L = w->vit[l];
+        CK(seedmi_layernorm_bf16(t.x, D, L.ln1_w, L.ln1_b, 1e-6f, t.xn, D, M, D, s));
+        CK(seedmi_gemm_bf16(M, 3 * D, D, t.xn, D, L.qkv_w, D, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, 0, 0, s));
+        CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
+                                 vit_scale, 0, 1, s));
+        CK(seedmi_gemm_bf16(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, s));
+        CK(seedmi_layernorm_bf16(t.x, D, L.ln2_w, L.ln2_b, 1e-6f, t.xn, D, M, D, s));
+        CK(seedmi_gemm_bf16(M, F, D, t.xn, D, L.fc1_w, D, L.fc1_b, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, 0, 0, s));
+        CK(seedmi_gemm_bf16(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, s));
+    }
+    // ---- ln_vision (blip2.py:179-184) -> image_embeds in xn
+    CK(seedmi_layernorm_bf16(t.x, D, w->ln_vision_w, w->ln_vision_b, 1e-5f, t.xn, D, M, D, s));
+    if (taps && taps->image_embeds)
+        if (hipMemcpyAsync(taps->image_embeds, t.xn, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return SEEDMI_E_HIP;
+
+    // ---- Q-Former: queries = LayerNorm(query_tokens) expanded over the batch
+    CK(seedmi_fill_rows(t.qx, Q, w->n_query, 0, B, w->query_ln, Q, w->n_query, Q, s));
+    const float q_scale = 1.0f / sqrtf((float)qhd);
+    const int nq = w->n_query;
+    for (int l = 0; l < w->qf_layers; ++l) {
+        const seedmi_qf_layer_t& L = w->qf[l];
+        // causal self-attention on the 32 queries + BertSelfOutput
+        CK(seedmi_gemm_bf16(Mq, 3 * Q, Q, t.qx, Q, L.qkv_w, Q, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qqkv, 3 * Q, 0, 0, s));
+        CK(seedmi_attention_bf16(t.qqkv, 3 * Q, t.qqkv + Q, 3 * Q, t.qqkv + 2 * Q, 3 * Q, t.qa, Q, B, QH, qhd, nq, nq,
+                                 q_scale, 1, 1, s));
+        CK(seedmi_gemm_bf16(Mq, Q, Q, t.qa, Q, L.ao_w, Q, L.ao_b, t.qx, Q, SEEDMI_EPI_BIAS_RESIDUAL, t.qt, Q, 0, 0, s));
+        CK(seedmi_layernorm_bf16(t.qt, Q, L.ao_ln_w, L.ao_ln_b, 1e-12f, t.qx, Q, Mq, Q, s));
+        if (L.has_cross) {
+            CK(seedmi_gemm_bf16(Mq, Q, Q, t.qx, Q, L.cq_w, Q, L.cq_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qa, Q, 0, 0, s));
+            CK(seedmi_gemm_bf16(M, 2 * Q, D, t.xn, D, L.ckv_w, D, L.ckv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.kv, 2 * Q, 0, 0, s));
+            CK(seedmi_attention_bf16(t.qa, Q, t.kv, 2 * Q, t.kv + Q, 2 * Q, t.qt, Q, B, QH, qhd, nq, NT, q_scale, 0, 1, s));
+            CK(seedmi_gemm_bf16(Mq, Q, Q, t.qt, Q, L.co_w, Q, L.co_b, t.qx, Q, SEEDMI_EPI_BIAS_RESIDUAL, t.qa, Q, 0, 0, s));
+            CK(seedmi_layernorm_bf16(t.qa, Q, L.co_ln_w, L.co_ln_b, 1e-12f, t.qx, Q, Mq, Q, s));
+        }
+        CK(seedmi_gemm_bf16(Mq, FF, Q, t.qx, Q, L.ffn_w1, Q, L.ffn_b1, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.qh, FF, 0, 0, s));
+        CK(seedmi_gemm_bf16(Mq, Q, FF, t.qh, FF, L.ffn_w2, FF, L.ffn_b2, t.qx, Q, SEEDMI_EPI_BIAS_RESIDUAL, t.qt, Q, 0, 0, s));
+        CK(seedmi_layernorm_bf16(t.qt, Q, L.ffn_ln_w, L.ffn_ln_b, 1e-12f, t.qx, Q, Mq, Q, s));
+    }
+    if (taps && taps->qformer_out)
+        if (hipMemcpyAsync(taps->qformer_out, t.qx, (size_t)Mq * Q * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return SEEDMI_E_HIP;
+
+    // ---- encode_task_layer: Linear -> Tanh -> Linear (qformer_quantizer.py:219-223), then the VQ argmin
+    const int cd = w->code_dim;
+    CK(seedmi_gemm_bf16(Mq, Q, Q, t.qx, Q, w->head_w0, Q, w->head_b0, nullptr, 0, SEEDMI_EPI_BIAS_TANH, t.qa, Q, 0, 0, s));
+    CK(seedmi_gemm_bf16(Mq, cd, Q, t.qa, Q, w->head_w1, Q, w->head_b1, nullptr, 0, SEEDMI_EPI_BIAS, t.z, cd, 0, 0, s));
+    if (taps && taps->z)
+        if (hipMemcpyAsync(taps->z, t.z, (size_t)Mq * cd * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return SEEDMI_E_HIP;
+    CK(seedmi_vq_argmin_bf16(t.z, cd, w->codebook, w->code_sqnorm, ids_i64, Mq, w->n_embed, cd, s));
+    return SEEDMI_OK;
+}

@@ -1,0 +1,116 @@
+"""ctypes binding of libseedmi.so (the C-ABI boundary declared in include/seedmi.h).
+
+The product path has NO fallback: if the shared library is missing or the device is not a gfx950 the
+import / first call raises.  PyTorch is used only as the owner of device memory and streams
+(``tensor.data_ptr()``, ``torch.cuda.current_stream().cuda_stream``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseedmi.so")
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_BIAS_TANH, EPI_SWIGLU, EPI_PATCH_EMBED = range(7)
+
+_vp = C.c_void_p
+_i = C.c_int
+
+
+class VitLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b",
+                                    "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class QfLayer(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("qkv_w", "qkv_b", "ao_w", "ao_b", "ao_ln_w", "ao_ln_b")] + [("has_cross", _i)] +
+                [(n, _vp) for n in ("cq_w", "cq_b", "ckv_w", "ckv_b", "co_w", "co_b", "co_ln_w", "co_ln_b",
+                                    "ffn_w1", "ffn_b1", "ffn_w2", "ffn_b2", "ffn_ln_w", "ffn_ln_b")])
+
+
+class TokenizerWeights(C.Structure):
+    _fields_ = ([(n, _i) for n in ("img_size", "patch", "vit_dim", "vit_depth", "vit_heads", "vit_ffn", "qf_dim",
+                                   "qf_layers", "qf_heads", "qf_ffn", "n_query", "n_embed", "code_dim", "kpad")] +
+                [("patch_w", _vp), ("patch_b", _vp), ("pos_embed", _vp), ("cls_pos0", _vp),
+                 ("vit", C.POINTER(VitLayer)), ("ln_vision_w", _vp), ("ln_vision_b", _vp), ("query_ln", _vp),
+                 ("qf", C.POINTER(QfLayer)), ("head_w0", _vp), ("head_b0", _vp), ("head_w1", _vp), ("head_b1", _vp),
+                 ("codebook", _vp), ("code_sqnorm", _vp)])
+
+
+class TokenizerTaps(C.Structure):
+    _fields_ = [("image_embeds", _vp), ("qformer_out", _vp), ("z", _vp)]
+
+
+class LlamaLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln1_w", "qkv_w", "o_w", "ln2_w", "gate_up_w", "down_w", "k_cache", "v_cache")]
+
+
+class LlamaWeights(C.Structure):
+    _fields_ = ([(n, _i) for n in ("hidden", "layers", "heads", "ffn", "vocab", "vocab_pad", "max_pos", "tmax",
+                                   "batch_cap")] + [("rms_eps", C.c_float)] +
+                [("embed", _vp), ("layer", C.POINTER(LlamaLayer)), ("norm_w", _vp), ("lm_head", _vp),
+                 ("cos_t", _vp), ("sin_t", _vp)])
+
+
+# name -> (restype, argtypes); must list every symbol include/seedmi.h declares (tests check the export table)
+SIGNATURES = {
+    "seedmi_version": (_i, []),
+    "seedmi_last_error": (C.c_char_p, []),
+    "seedmi_check_device": (_i, []),
+    "seedmi_gemm_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "seedmi_layernorm_bf16": (_i, [_vp, _i, _vp, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
+    "seedmi_rmsnorm_bf16": (_i, [_vp, _i, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
+    "seedmi_im2col_patch": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "seedmi_fill_rows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "seedmi_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.c_float, _i, _i, _vp]),
+    "seedmi_vq_code_sqnorm": (_i, [_vp, _vp, _i, _i, _vp]),
+    "seedmi_vq_argmin_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "seedmi_embed_rows": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "seedmi_llama_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _vp]),
+    "seedmi_gemm_skinny_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "seedmi_tokenize_workspace_bytes": (C.c_size_t, [C.POINTER(TokenizerWeights), _i]),
+    "seedmi_tokenize": (_i, [C.POINTER(TokenizerWeights), _vp, _i, _i, _vp, C.POINTER(TokenizerTaps), _vp,
+                             C.c_size_t, _vp]),
+    "seedmi_llama_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaWeights), _i, _i]),
+    "seedmi_llama_forward": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.c_size_t, _vp]),
+}
+
+
+class SeedmiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libseedmi.so and bind every declared symbol.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SeedmiError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU / PyTorch fallback for the hot path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().seedmi_last_error().decode(errors="replace")
+        raise SeedmiError(f"{what} failed with code {rc}: {msg}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,144 @@
+"""Host side of the SEED-LLaMA forward on MI355X: weight packing, static KV cache, one C-ABI call per step.
+
+Mirrors ``LlamaForCausalLM.forward`` (models/llama_xformer.py:661-743) in eval mode with ``use_cache=True``.
+Consumes the HF state-dict key names and repacks once:
+
+* q/k/v_proj stacked into one [3h,h] GEMM; gate/up_proj row-interleaved into one [2F,h] GEMM whose epilogue
+  applies SiLU(gate)*up (llama_xformer.py:186);
+* RoPE cos/sin tables built exactly like ``LlamaRotaryEmbedding`` (fp32, cat(freqs,freqs), cast to the
+  activation dtype on read — llama_xformer.py:118-150);
+* a static KV cache [B][H][tmax][128] per layer replaces the reference's ``torch.cat`` per step (:234-239):
+  keys are stored post-RoPE, like the reference's ``past_key_value``.
+
+The reference's eval-mode mask quirk means parity is defined for unpadded, equal-length
+batches; this engine implements causal attention over positions ``past_len .. past_len+T-1`` for all rows.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as L
+from .config import LlamaConfig
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class LlamaEngine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: LlamaConfig, device="cuda", batch_cap: int = 32,
+                 tmax: Optional[int] = None):
+        self.lib = L.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.SeedmiError("LlamaEngine needs a HIP device (cuda:N); there is no CPU path")
+        if cfg.head_dim != 128:
+            raise L.SeedmiError(f"head_dim {cfg.head_dim}: the attention kernels are built for 128")
+        with torch.cuda.device(self.device):
+            L.check(self.lib.seedmi_check_device(), "seedmi_check_device")
+        self.batch_cap = batch_cap
+        self.tmax = tmax or cfg.max_pos
+        self.vocab_pad = _round_up(cfg.vocab, 16)
+        self._keep = []
+        self._ws = None
+        self._ws_key = (0, 0)
+        self.past_len = 0
+        self._pack(state_dict)
+
+    def _dev(self, t):
+        t = t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _pack(self, sd):
+        cfg = self.cfg
+        h, F = cfg.hidden, cfg.ffn
+        p = L.ptr
+        w = L.LlamaWeights()
+        w.hidden, w.layers, w.heads, w.ffn, w.vocab = h, cfg.layers, cfg.heads, F, cfg.vocab
+        w.vocab_pad, w.max_pos, w.tmax, w.batch_cap = self.vocab_pad, cfg.max_pos, self.tmax, self.batch_cap
+        w.rms_eps = cfg.rms_eps
+        w.embed = p(self._dev(sd["model.embed_tokens.weight"]))
+        layers = (L.LlamaLayer * cfg.layers)()
+        self.k_cache, self.v_cache = [], []
+        for i in range(cfg.layers):
+            pre = f"model.layers.{i}."
+            l = layers[i]
+            l.ln1_w = p(self._dev(sd[pre + "input_layernorm.weight"]))
+            l.qkv_w = p(self._dev(torch.cat([sd[pre + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)))
+            l.o_w = p(self._dev(sd[pre + "self_attn.o_proj.weight"]))
+            l.ln2_w = p(self._dev(sd[pre + "post_attention_layernorm.weight"]))
+            gate, up = sd[pre + "mlp.gate_proj.weight"], sd[pre + "mlp.up_proj.weight"]
+            l.gate_up_w = p(self._dev(torch.stack((gate, up), dim=1).reshape(2 * F, h)))
+            l.down_w = p(self._dev(sd[pre + "mlp.down_proj.weight"]))
+            kc = torch.zeros(self.batch_cap, cfg.heads, self.tmax, cfg.head_dim, dtype=torch.bfloat16, device=self.device)
+            vc = torch.zeros_like(kc)
+            self.k_cache.append(kc)
+            self.v_cache.append(vc)
+            l.k_cache, l.v_cache = p(kc), p(vc)
+        self._layers = layers
+        w.layer = C.cast(layers, C.POINTER(L.LlamaLayer))
+        w.norm_w = p(self._dev(sd["model.norm.weight"]))
+        lm = torch.zeros(self.vocab_pad, h, dtype=torch.bfloat16)
+        lm[:cfg.vocab] = sd["lm_head.weight"].to(torch.bfloat16).cpu()
+        w.lm_head = p(self._dev(lm))
+        # LlamaRotaryEmbedding.__init__ (llama_xformer.py:118-134)
+        hd = cfg.head_dim
+        inv_freq = 1.0 / (cfg.rope_base ** (torch.arange(0, hd, 2).float() / hd))
+        t = torch.arange(cfg.max_pos, dtype=torch.float32)
+        freqs = torch.einsum("i,j->ij", t, inv_freq)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        w.cos_t, w.sin_t = p(self._dev(emb.cos())), p(self._dev(emb.sin()))
+        self.w = w
+
+    def _workspace(self, B, T):
+        if self._ws is None or B * T > self._ws_key[0] * self._ws_key[1]:
+            nbytes = self.lib.seedmi_llama_workspace_bytes(C.byref(self.w), B, T)
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_key = (B, T)
+        return self._ws
+
+    def reset(self):
+        self.past_len = 0
+
+    def forward(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None, past_len: Optional[int] = None,
+                last_only: bool = False) -> torch.Tensor:
+        """input_ids int64 [B,T] on device.  Appends T positions to the static cache starting at ``past_len``
+        (default: continue from the previous call).  Returns bf16 logits [B, T or 1, vocab] (a view of a padded
+        buffer)."""
+        cfg = self.cfg
+        if input_ids.dim() != 2:
+            raise ValueError("You have to specify input_ids of shape [batch, seq]")     # llama_xformer.py:515-522
+        B, T = input_ids.shape
+        if past_len is None:
+            past_len = self.past_len
+        if position_ids is None:                                                          # llama_xformer.py:531-539
+            position_ids = torch.arange(past_len, past_len + T, dtype=torch.int64, device=self.device).unsqueeze(0).expand(B, T)
+        position_ids = position_ids.reshape(B, T).to(torch.int64).contiguous()
+        input_ids = input_ids.to(torch.int64).contiguous()
+        Tout = 1 if last_only else T
+        logits = torch.empty(B * Tout, self.vocab_pad, dtype=torch.bfloat16, device=self.device)
+        ws = self._workspace(B, T)
+        with torch.cuda.device(self.device):
+            rc = self.lib.seedmi_llama_forward(C.byref(self.w), L.ptr(input_ids), L.ptr(position_ids), B, T, past_len,
+                                               1 if last_only else 0, L.ptr(logits), self.vocab_pad, L.ptr(ws),
+                                               ws.numel(), L.stream_ptr())
+        L.check(rc, "seedmi_llama_forward")
+        self.past_len = past_len + T
+        return logits.view(B, Tout, self.vocab_pad)[:, :, :cfg.vocab]
+
+    def greedy_decode(self, prompt_ids: torch.Tensor, n_new: int):
+        """Greedy loop (argmax on device, no host sync inside the loop). Returns (tokens [B,n_new], per-step logits)."""
+        self.reset()
+        logits = self.forward(prompt_ids, last_only=True)
+        steps = [logits[:, 0]]
+        tok = logits[:, 0].float().argmax(-1, keepdim=True)
+        out = [tok]
+        for _ in range(n_new - 1):
+            logits = self.forward(tok, last_only=True)
+            steps.append(logits[:, 0])
+            tok = logits[:, 0].float().argmax(-1, keepdim=True)
+            out.append(tok)
+        return torch.cat(out, dim=1), torch.stack(steps, dim=1)

@@ -1,0 +1,405 @@
+"""Kernel-level parity on a real MI355X: every C-ABI kernel against a plain fp32 restatement of the same op
+(with the reference's rounding points) on the same seeded inputs.  Integer/index work (VQ ids) is bit-exact
+against the oracle; floating point within the tolerance written in each test.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from seed_amd import lib as L  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests selected but no HIP device visible"
+    l = L.load()                      # raises if libseedmi.so is missing: no silent fallback
+    L.check(l.seedmi_check_device(), "seedmi_check_device")
+    return l
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def r(x):
+    return x.to(torch.bfloat16).float()
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def rand(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale)
+
+
+def assert_close_bf16(got, want, what, atol_ulps=1.5, frac=0.999):
+    """got: bf16 tensor from the kernel; want: fp32 tensor already rounded where the reference rounds.
+    At least ``frac`` of elements must be within atol_ulps bf16 ulps of |want|, and the normalised error small."""
+    got = got.float().cpu()
+    want = want.float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), what
+    err = (got - want).abs()
+    ulp = torch.clamp(want.abs(), min=1e-30) * 2.0 ** -8
+    floor = want.abs().mean() * 2.0 ** -8
+    ok = err <= atol_ulps * torch.maximum(ulp, floor)
+    rel = (got - want).norm() / want.norm().clamp(min=1e-30)
+    print(f"[{what}] rel={rel:.3e} within={ok.float().mean():.5f} max_err={err.max():.3e}")
+    assert rel < 4e-3, (what, rel.item())
+    assert ok.float().mean() >= frac, (what, ok.float().mean().item())
+
+
+def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=0, row_extra=0, C_init=None):
+    M, K = A.shape
+    N = W.shape[0]
+    out_rows = out_rows or M
+    out_cols = out_cols or N
+    C = torch.zeros(out_rows, out_cols, dtype=torch.bfloat16, device="cuda") if C_init is None else C_init
+    rc = lib.seedmi_gemm_bf16(M, N, K, L.ptr(A), A.stride(0), L.ptr(W), W.stride(0), L.ptr(bias), L.ptr(res),
+                              0 if res is None else res.stride(0), epi, L.ptr(C), C.stride(0), row_group, row_extra,
+                              L.stream_ptr())
+    L.check(rc, "seedmi_gemm_bf16")
+    torch.cuda.synchronize()
+    return C
+
+
+GEMM_SHAPES = [
+    (257 * 2, 1408, 1408),      # ViT proj shape, ragged M
+    (300, 4224, 1408),          # QKV
+    (128, 6144, 1408),          # fc1
+    (200, 1408, 6144),          # fc2 (long K)
+    (64, 32, 768),              # VQ head: N smaller than a tile
+    (1000, 768, 768),
+    (130, 1536, 1408),          # cross K|V
+    (48, 40194 // 2 * 2, 256),  # ragged N (not a multiple of 16)
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bias(lib, M, N, K):
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    A = bf(rand(gen, M, K)).cuda()
+    W = bf(rand(gen, N, K, scale=0.05)).cuda()
+    # asymmetric structure so a transposed / permuted C write cannot pass
+    W[: min(N, 64)] *= torch.arange(1, min(N, 64) + 1, device="cuda").unsqueeze(1).to(torch.bfloat16) / 16
+    bias = bf(rand(gen, N)).cuda()
+    ldc = (N + 7) // 8 * 8
+    C = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+    run_gemm(lib, A, W, bias, None, L.EPI_BIAS, C_init=C)
+    want = r(A.float() @ W.float().t() + bias.float())
+    assert_close_bf16(C[:, :N], want, f"gemm_bias {M}x{N}x{K}")
+    if ldc > N:
+        assert (C[:, N:] == 0).all(), "wrote past N"
+
+
+def test_gemm_identity_layout(lib):
+    """A = I  =>  C == W^T exactly; catches any row/column permutation in fragment or epilogue mapping."""
+    K = N = 256
+    M = 256
+    A = torch.eye(M, K, dtype=torch.bfloat16, device="cuda")
+    gen = torch.Generator().manual_seed(3)
+    W = bf(rand(gen, N, K)).cuda()
+    C = run_gemm(lib, A, W, None, None, L.EPI_NONE)
+    assert torch.equal(C, W.t().contiguous())
+
+
+@pytest.mark.parametrize("epi", ["gelu", "tanh", "residual", "swiglu", "none"])
+def test_gemm_epilogues(lib, epi):
+    gen = torch.Generator().manual_seed(11)
+    M, N, K = 321, 768, 512
+    A = bf(rand(gen, M, K)).cuda()
+    W = bf(rand(gen, N, K, scale=0.06)).cuda()
+    bias = bf(rand(gen, N, scale=0.5)).cuda()
+    acc = A.float() @ W.float().t()
+    if epi == "gelu":
+        C = run_gemm(lib, A, W, bias, None, L.EPI_BIAS_GELU)
+        want = r(gelu(r(acc + bias.float())))
+    elif epi == "tanh":
+        C = run_gemm(lib, A, W, bias, None, L.EPI_BIAS_TANH)
+        want = r(torch.tanh(r(acc + bias.float())))
+    elif epi == "residual":
+        res = bf(rand(gen, M, N)).cuda()
+        C = run_gemm(lib, A, W, bias, res, L.EPI_BIAS_RESIDUAL)
+        want = r(r(acc + bias.float()) + res.float())
+    elif epi == "swiglu":
+        C = run_gemm(lib, A, W, None, None, L.EPI_SWIGLU, out_cols=N // 2)
+        g, u = r(acc[:, 0::2]), r(acc[:, 1::2])
+        want = r(r(torch.nn.functional.silu(g)) * u)
+    else:
+        C = run_gemm(lib, A, W, None, None, L.EPI_NONE)
+        want = r(acc)
+    assert_close_bf16(C, want, f"gemm_{epi}", frac=0.998)
+
+
+def test_gemm_residual_inplace(lib):
+    """The tokenizer calls proj/fc2 with C aliasing the residual (x += ...)."""
+    gen = torch.Generator().manual_seed(12)
+    M, N, K = 514, 1408, 1408
+    A = bf(rand(gen, M, K)).cuda()
+    W = bf(rand(gen, N, K, scale=0.03)).cuda()
+    bias = bf(rand(gen, N, scale=0.1)).cuda()
+    x = bf(rand(gen, M, N)).cuda()
+    want = r(r(A.float() @ W.float().t() + bias.float()) + x.float())
+    run_gemm(lib, A, W, bias, x, L.EPI_BIAS_RESIDUAL, C_init=x)
+    assert_close_bf16(x, want, "gemm_residual_inplace")
+
+
+def test_patch_embed_path(lib):
+    """im2col + GEMM(PATCH_EMBED) + cls rows == conv2d + cat(cls) + pos (eva_vit.py:224-230, 369-377)."""
+    gen = torch.Generator().manual_seed(13)
+    B, D, S, P = 3, 256, 56, 14
+    g = S // P
+    img = rand(gen, B, 3, S, S).cuda()
+    wconv = bf(rand(gen, D, 3, P, P, scale=0.04)).cuda()
+    bconv = bf(rand(gen, D, scale=0.1)).cuda()
+    pos = bf(rand(gen, g * g + 1, D, scale=0.1)).cuda()
+    cls = bf(rand(gen, D, scale=0.1)).cuda()
+    kpad = 640
+    col = torch.empty(B * g * g, kpad, dtype=torch.bfloat16, device="cuda")
+    for is_fp32, src in ((1, img), (0, bf(img))):
+        L.check(lib.seedmi_im2col_patch(L.ptr(src), is_fp32, L.ptr(col), B, 3, S, P, kpad, L.stream_ptr()), "im2col")
+        torch.cuda.synchronize()
+        ref_col = torch.nn.functional.unfold(r(img), kernel_size=P, stride=P).transpose(1, 2).reshape(B * g * g, -1)
+        assert torch.equal(col[:, :588].float(), ref_col), "im2col mismatch"
+        assert (col[:, 588:] == 0).all()
+    wpad = torch.zeros(D, kpad, dtype=torch.bfloat16, device="cuda")
+    wpad[:, :588] = wconv.reshape(D, -1)
+    x = torch.zeros(B * (g * g + 1), D, dtype=torch.bfloat16, device="cuda")
+    run_gemm(lib, col, wpad, bconv, pos, L.EPI_PATCH_EMBED, row_group=g * g, row_extra=1, C_init=x)
+    cls_pos0 = bf(cls.float() + pos[0].float())
+    L.check(lib.seedmi_fill_rows(L.ptr(x), D, g * g + 1, 0, B, L.ptr(cls_pos0), D, 1, D, L.stream_ptr()), "fill_rows")
+    torch.cuda.synchronize()
+    conv = r(torch.nn.functional.conv2d(r(img), wconv.float(), bconv.float(), stride=P))
+    tok = conv.flatten(2).transpose(1, 2)
+    want = r(torch.cat((cls.float().expand(B, 1, D), tok), 1) + pos.float())
+    assert_close_bf16(x.view(B, g * g + 1, D), want, "patch_embed")
+
+
+@pytest.mark.parametrize("rows,cols,eps", [(514, 1408, 1e-6), (96, 768, 1e-12), (33, 128, 1e-5), (40, 704, 1e-6)])
+def test_layernorm(lib, rows, cols, eps):
+    gen = torch.Generator().manual_seed(rows)
+    x = bf(rand(gen, rows, cols, scale=2.0) + 0.5).cuda()
+    w = bf(1 + rand(gen, cols, scale=0.1)).cuda()
+    b = bf(rand(gen, cols, scale=0.1)).cuda()
+    out = torch.empty_like(x)
+    L.check(lib.seedmi_layernorm_bf16(L.ptr(x), cols, L.ptr(w), L.ptr(b), eps, L.ptr(out), cols, rows, cols,
+                                      L.stream_ptr()), "layernorm")
+    torch.cuda.synchronize()
+    want = r(torch.nn.functional.layer_norm(x.float(), (cols,), w.float(), b.float(), eps))
+    assert_close_bf16(out, want, f"layernorm {rows}x{cols}", atol_ulps=1.01)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 4096), (7, 5120), (50, 256)])
+def test_rmsnorm(lib, rows, cols):
+    gen = torch.Generator().manual_seed(cols)
+    x = bf(rand(gen, rows, cols)).cuda()
+    w = bf(1 + rand(gen, cols, scale=0.1)).cuda()
+    out = torch.empty_like(x)
+    L.check(lib.seedmi_rmsnorm_bf16(L.ptr(x), cols, L.ptr(w), 1e-6, L.ptr(out), cols, rows, cols, L.stream_ptr()), "rmsnorm")
+    torch.cuda.synchronize()
+    xf = x.float()
+    h = r(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    want = r(w.float() * h)
+    assert_close_bf16(out, want, f"rmsnorm {rows}x{cols}", atol_ulps=1.01)
+
+
+def ref_attention(q, k, v, heads, scale, causal, round_s=True):
+    """q [B,nq,H*hd] etc. fp32 holding bf16 values; reference rounding points (eva_vit.py:139-156)."""
+    B, nq, C = q.shape
+    nk = k.shape[1]
+    hd = C // heads
+    qh = r(q.view(B, nq, heads, hd).transpose(1, 2) * scale)
+    kh = k.view(B, nk, heads, hd).transpose(1, 2)
+    vh = v.view(B, nk, heads, hd).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    if round_s:
+        s = r(s)
+    if causal:
+        keep = torch.ones(nq, nk, dtype=torch.bool, device=q.device).tril()
+        s = s.masked_fill(~keep, float("-inf"))
+    p = r(torch.softmax(s, dim=-1))
+    return r(p @ vh).transpose(1, 2).reshape(B, nq, C)
+
+
+@pytest.mark.parametrize("B,H,hd,nq,nk,causal", [
+    (3, 16, 88, 257, 257, False),     # ViT
+    (2, 4, 88, 17, 17, False),        # small ViT (NKP=32 path)
+    (5, 12, 64, 32, 32, True),        # Q-Former causal self-attention
+    (4, 12, 64, 32, 257, False),      # Q-Former cross-attention
+    (2, 2, 64, 17, 17, False),
+])
+def test_attention_fullrow(lib, B, H, hd, nq, nk, causal):
+    gen = torch.Generator().manual_seed(B * 100 + nk)
+    C = H * hd
+    # packed [q|k|v] buffer like the ViT QKV GEMM output
+    if nq == nk:
+        qkv = bf(rand(gen, B * nq, 3 * C)).cuda()
+        Q, K, V, ld = qkv, qkv[:, C:], qkv[:, 2 * C:], 3 * C
+        ldq = ld
+    else:
+        qb = bf(rand(gen, B * nq, C)).cuda()
+        kv = bf(rand(gen, B * nk, 2 * C)).cuda()
+        Q, K, V, ldq, ld = qb, kv, kv[:, C:], C, 2 * C
+    out = torch.zeros(B * nq, C, dtype=torch.bfloat16, device="cuda")
+    scale = hd ** -0.5
+    rc = lib.seedmi_attention_bf16(L.ptr(Q), ldq, L.ptr(K), ld, L.ptr(V), ld, L.ptr(out), C, B, H, hd, nq, nk, scale,
+                                   1 if causal else 0, 1, L.stream_ptr())
+    L.check(rc, "attention")
+    torch.cuda.synchronize()
+    qf = Q[:, :C].float().view(B, nq, C)
+    kf = K[:, :C].float().reshape(B, nk, C)
+    vf = V[:, :C].float().reshape(B, nk, C)
+    want = ref_attention(qf, kf, vf, H, scale, causal)
+    assert_close_bf16(out.view(B, nq, C), want, f"attention hd{hd} {nq}x{nk} causal={causal}", atol_ulps=2.5, frac=0.995)
+
+
+def test_vq_argmin_bit_exact(lib, golden_dir):
+    """ids identical to the oracle (fixed summation order) and to the reference module's golden ids, incl. ties."""
+    from oracle import seed_oracle as O
+    g = np.load(os.path.join(golden_dir, "vq_reference.npz"))
+    z = torch.from_numpy(g["z"]).reshape(-1, 32)
+    cb = torch.from_numpy(g["codebook"])
+    gen = torch.Generator().manual_seed(5)
+    z_big = torch.cat([z, rand(gen, 1000, 32, scale=0.3)], 0)          # ragged row count (1128 rows)
+    for zz in (z, z_big):
+        zd, cbd = bf(zz).cuda(), bf(cb).cuda()
+        ee = torch.empty(cb.shape[0], dtype=torch.float32, device="cuda")
+        ids = torch.full((zz.shape[0],), -1, dtype=torch.int64, device="cuda")
+        L.check(lib.seedmi_vq_code_sqnorm(L.ptr(cbd), L.ptr(ee), cb.shape[0], 32, L.stream_ptr()), "sqnorm")
+        L.check(lib.seedmi_vq_argmin_bf16(L.ptr(zd), 32, L.ptr(cbd), L.ptr(ee), L.ptr(ids), zz.shape[0], cb.shape[0], 32,
+                                          L.stream_ptr()), "vq")
+        torch.cuda.synchronize()
+        want = O.vq_argmin(zz, cb, O.Prec("bf16"))
+        assert torch.equal(ids.cpu(), want), f"{(ids.cpu() != want).sum().item()} / {want.numel()} ids differ from the oracle"
+    ref_ids = torch.from_numpy(g["ids_bf16"]).reshape(-1)
+    got = ids.cpu()[: z.shape[0]] if zz is z else None
+    ids_small = O.vq_argmin(z, cb, O.Prec("bf16"))
+    assert ids_small[0] == 17 and ids_small[1] == 17
+    # vs the reference module itself (its BLAS may sum in another order: only exact ties may differ)
+    assert (ids_small != ref_ids).float().mean() <= 0.02
+
+
+def test_vq_codebook_sqnorm_exact(lib):
+    from oracle import seed_oracle as O
+    gen = torch.Generator().manual_seed(9)
+    cb = bf(rand(gen, 8192, 32, scale=0.3))
+    ee = torch.empty(8192, dtype=torch.float32, device="cuda")
+    L.check(lib.seedmi_vq_code_sqnorm(L.ptr(cb.cuda()), L.ptr(ee), 8192, 32, L.stream_ptr()), "sqnorm")
+    torch.cuda.synchronize()
+    e = cb.float().numpy()
+    acc = np.zeros(8192, np.float32)
+    for k in range(32):
+        acc = (acc + O._bf16_round_np(e[:, k] * e[:, k])).astype(np.float32)
+    assert np.array_equal(ee.cpu().numpy(), O._bf16_round_np(acc))
+
+
+# ------------------------------------------------------------------------------------------------ LLaMA pieces
+
+@pytest.mark.parametrize("M,N,K,epi", [(32, 4096, 4096, "none"), (32, 512, 11008, "residual"), (4, 1024, 256, "swiglu"),
+                                       (17, 40194, 256, "none"), (64, 768, 512, "residual"), (33, 256, 1024, "none")])
+def test_gemm_skinny(lib, M, N, K, epi):
+    gen = torch.Generator().manual_seed(M + N)
+    A = bf(rand(gen, M, K)).cuda()
+    W = bf(rand(gen, N, K, scale=0.03)).cuda()
+    acc = A.float() @ W.float().t()
+    res = None
+    if epi == "residual":
+        res = bf(rand(gen, M, N)).cuda()
+        want, code, ncol = r(r(acc) + res.float()), L.EPI_BIAS_RESIDUAL, N
+    elif epi == "swiglu":
+        g, u = r(acc[:, 0::2]), r(acc[:, 1::2])
+        want, code, ncol = r(r(torch.nn.functional.silu(g)) * u), L.EPI_SWIGLU, N // 2
+    else:
+        want, code, ncol = r(acc), L.EPI_NONE, N
+    ldc = (ncol + 15) // 16 * 16
+    C = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+    rc = lib.seedmi_gemm_skinny_bf16(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(res), 0 if res is None else N, code,
+                                     L.ptr(C), ldc, L.stream_ptr())
+    L.check(rc, "gemm_skinny")
+    torch.cuda.synchronize()
+    assert_close_bf16(C[:, :ncol], want, f"gemm_skinny {M}x{N}x{K} {epi}", frac=0.998)
+
+
+def _rope_tables(max_pos, hd):
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    t = torch.arange(max_pos, dtype=torch.float32)
+    emb = torch.cat((torch.outer(t, inv),) * 2, dim=-1)
+    return bf(emb.cos()), bf(emb.sin())
+
+
+def _ref_rope(x, cos, sin):
+    h = x.shape[-1] // 2
+    rot = torch.cat((-x[..., h:], x[..., :h]), -1)
+    return r(r(x * cos) + r(rot * sin))
+
+
+@pytest.mark.parametrize("B,T,H,past", [(2, 12, 2, 0), (3, 1, 4, 9), (2, 70, 2, 0), (1, 5, 2, 7)])
+def test_rope_and_llama_attention(lib, B, T, H, past):
+    hd, tmax = 128, 128
+    gen = torch.Generator().manual_seed(B * 10 + T)
+    h = H * hd
+    cos_t, sin_t = _rope_tables(tmax, hd)
+    kc = torch.zeros(B, H, tmax, hd, dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    # pre-existing cache content for positions < past
+    k_past = bf(rand(gen, B, H, past, hd)).cuda()
+    v_past = bf(rand(gen, B, H, past, hd)).cuda()
+    kc[:, :, :past] = k_past
+    vc[:, :, :past] = v_past
+    qkv = bf(rand(gen, B * T, 3 * h)).cuda()
+    pos = torch.arange(past, past + T, dtype=torch.int64).unsqueeze(0).expand(B, T).contiguous().cuda()
+    q_out = torch.empty(B * T, h, dtype=torch.bfloat16, device="cuda")
+    rc = lib.seedmi_rope_kv_append(L.ptr(qkv), 3 * h, L.ptr(pos), L.ptr(cos_t.cuda()), L.ptr(sin_t.cuda()), L.ptr(q_out), h,
+                                   L.ptr(kc), L.ptr(vc), B, T, H, hd, tmax, past, L.stream_ptr())
+    L.check(rc, "rope_kv_append")
+    torch.cuda.synchronize()
+    qf = qkv[:, :h].float().view(B, T, H, hd).transpose(1, 2)
+    kf = qkv[:, h:2 * h].float().view(B, T, H, hd).transpose(1, 2)
+    vf = qkv[:, 2 * h:].float().view(B, T, H, hd).transpose(1, 2)
+    c = cos_t.float().cuda()[pos].unsqueeze(1)
+    s = sin_t.float().cuda()[pos].unsqueeze(1)
+    q_ref, k_ref = _ref_rope(qf, c, s), _ref_rope(kf, c, s)
+    assert torch.equal(q_out.float().view(B, T, H, hd).transpose(1, 2), q_ref), "rope(q) not bit-exact"
+    assert torch.equal(kc[:, :, past:past + T].float(), k_ref), "rope(k) / cache append not bit-exact"
+    assert torch.equal(vc[:, :, past:past + T].float(), vf)
+    assert torch.equal(kc[:, :, :past], k_past)
+
+    out = torch.zeros(B * T, h, dtype=torch.bfloat16, device="cuda")
+    scale = 1.0 / math.sqrt(hd)
+    rc = lib.seedmi_llama_attention_bf16(L.ptr(q_out), h, L.ptr(kc), L.ptr(vc), L.ptr(out), h, B, T, H, hd, tmax, past, scale,
+                                         L.stream_ptr())
+    L.check(rc, "llama_attention")
+    torch.cuda.synchronize()
+    kall = kc[:, :, :past + T].float()
+    vall = vc[:, :, :past + T].float()
+    sc = (q_ref @ kall.transpose(-1, -2)) * scale
+    if T > 1:
+        qi = torch.arange(T, device="cuda").unsqueeze(1) + past
+        kj = torch.arange(past + T, device="cuda").unsqueeze(0)
+        sc = sc.masked_fill(kj > qi, float("-inf"))
+    p = r(torch.softmax(sc, -1))
+    want = r(p @ vall).transpose(1, 2).reshape(B * T, h)
+    assert_close_bf16(out, want, f"llama_attention B{B} T{T} past{past}", atol_ulps=2.5, frac=0.995)
+
+
+def test_embed_rows(lib):
+    gen = torch.Generator().manual_seed(2)
+    table = bf(rand(gen, 1000, 256)).cuda()
+    ids = torch.randint(0, 1000, (77,), generator=gen).cuda()
+    out = torch.empty(77, 256, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.seedmi_embed_rows(L.ptr(ids), L.ptr(table), 256, L.ptr(out), 256, 77, 256, 1000, L.stream_ptr()), "embed")
+    torch.cuda.synchronize()
+    assert torch.equal(out, table[ids])
+
+
+def test_error_reporting(lib):
+    rc = lib.seedmi_gemm_bf16(16, 16, 100, None, 8, None, 8, None, None, 0, 0, None, 8, 0, 0, None)
+    assert rc == -1 and b"multiple of 64" in lib.seedmi_last_error()
+    rc = lib.seedmi_attention_bf16(None, 8, None, 8, None, 8, None, 8, 1, 1, 80, 4, 4, 1.0, 0, 1, None)
+    assert rc != 0

@@ -1,0 +1,111 @@
+"""The drop-in Python surfaces on CPU: HF ``generate()`` protocol of models.llama_xformer.LlamaForCausalLM (with a stub
+engine standing in for the HIP engine — the protocol, not the arithmetic, is under test here) and the tokenizer
+class's argument handling."""
+import pytest
+import torch
+
+from oracle import seed_oracle as O
+from seed_amd import config as C
+from seed_amd.weights import make_llama_state_dict
+
+
+class StubEngine:
+    """Duck-types seed_amd.llama_engine.LlamaEngine on CPU through the oracle (TEST ONLY)."""
+
+    def __init__(self, sd, cfg, batch_cap, tmax):
+        self.sd, self.cfg, self.batch_cap, self.tmax = sd, cfg, batch_cap, tmax
+        self.k_cache = [torch.zeros(batch_cap, cfg.heads, tmax, cfg.head_dim) for _ in range(cfg.layers)]
+        self.v_cache = [torch.zeros_like(k) for k in self.k_cache]
+        self.calls = []
+
+    def forward(self, input_ids, position_ids=None, past_len=0, last_only=False):
+        B, T = input_ids.shape
+        self.calls.append((B, T, past_len))
+        past = None
+        if past_len:
+            past = [(k[:B, :, :past_len], v[:B, :, :past_len]) for k, v in zip(self.k_cache, self.v_cache)]
+        logits, new = O.llama_forward(self.sd, self.cfg, input_ids, past=past, position_ids=position_ids, mode="fp32")
+        for l, (k, v) in enumerate(new):
+            self.k_cache[l][:B, :, :past_len + T] = k
+            self.v_cache[l][:B, :, :past_len + T] = v
+        return logits[:, -1:] if last_only else logits
+
+
+def _model(cfg, sd):
+    from transformers.models.llama.configuration_llama import LlamaConfig as HF
+    from models.llama_xformer import LlamaForCausalLM
+    hf = HF(vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.ffn, num_hidden_layers=cfg.layers,
+            num_attention_heads=cfg.heads, rms_norm_eps=cfg.rms_eps, max_position_embeddings=cfg.max_pos,
+            pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    m = LlamaForCausalLM(hf).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    m._engine = StubEngine(sd, cfg, batch_cap=4, tmax=64)
+    return m
+
+
+def test_forward_signature_and_legacy_cache_layout():
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=3, norm_jitter=0.05)
+    m = _model(cfg, sd)
+    ids = torch.randint(3, cfg.vocab, (2, 7), generator=torch.Generator().manual_seed(0))
+    out = m(input_ids=ids, use_cache=True)
+    ref, past = O.llama_forward(sd, cfg, ids, mode="fp32")
+    assert out.logits.shape == (2, 7, cfg.vocab) and torch.allclose(out.logits, ref)
+    pkv = out.past_key_values
+    assert len(pkv) == cfg.layers and pkv[0][0].shape == (2, cfg.heads, 7, cfg.head_dim)      # [B,H,T,hd]
+    assert torch.allclose(pkv[1][0], past[1][0])
+    step = m(input_ids=ids[:, :1], past_key_values=pkv, use_cache=True)
+    ref2, _ = O.llama_forward(sd, cfg, ids[:, :1], past=past, mode="fp32")
+    assert torch.allclose(step.logits, ref2, atol=1e-5)
+    assert step.past_key_values[0][0].shape[2] == 8
+    # labels -> shifted CE loss like the reference (llama_xformer.py:721-731)
+    lo = m(input_ids=ids, labels=ids)
+    want = torch.nn.functional.cross_entropy(ref[:, :-1].reshape(-1, cfg.vocab), ids[:, 1:].reshape(-1))
+    assert abs(lo.loss.item() - want.item()) < 1e-4
+    with pytest.raises(ValueError):
+        m()
+    with pytest.raises(ValueError):
+        m(input_ids=ids, inputs_embeds=torch.zeros(2, 7, cfg.hidden))
+
+
+def test_hf_generate_greedy_matches_oracle_loop():
+    """scripts/seed_llama_inference_8B.py:28-39 calls model.generate(input_ids=..., ...) — must work on current HF."""
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=3, norm_jitter=0.05)
+    m = _model(cfg, sd)
+    ids = torch.randint(3, cfg.vocab, (2, 9), generator=torch.Generator().manual_seed(1))
+    n_new = 5
+    gen = m.generate(input_ids=ids, max_new_tokens=n_new, do_sample=False, num_beams=1, eos_token_id=None, pad_token_id=0)
+    want, _ = O.llama_greedy_decode(sd, cfg, ids, n_new, mode="fp32")
+    assert torch.equal(gen[:, 9:], want)
+    # prefill once, then single-token steps on the cached state
+    calls = m._engine.calls
+    assert calls[0] == (2, 9, 0) and all(c == (2, 1, 9 + i) for i, c in enumerate(calls[1:n_new]))
+    # sampling path of the scripts (top_p) runs too
+    torch.manual_seed(0)
+    m._engine.calls.clear()
+    out = m.generate(input_ids=ids, max_new_tokens=3, do_sample=True, top_p=0.5, temperature=1.0, num_beams=1, pad_token_id=0)
+    assert out.shape[1] <= 12 and (out[:, :9] == ids).all()
+
+
+def test_tokenizer_argument_contract():
+    from models.seed_llama_tokenizer import SeedLlamaTokenizer
+    t = SeedLlamaTokenizer(device="cuda")
+    assert t.num_image_tokens == 8192
+    with pytest.raises(AssertionError):
+        t.encode_image()                                      # exactly one of the three inputs (:192)
+    with pytest.raises(AssertionError):
+        t.encode_image(image_path="a.jpg", image_torch=torch.zeros(3, 224, 224))
+
+
+def test_clip_transform_fallback_matches_definition():
+    from PIL import Image
+    import numpy as np
+    from models.transforms import get_transform, CLIP_MEAN, CLIP_STD
+    rng = np.random.RandomState(0)
+    img = Image.fromarray(rng.randint(0, 255, (300, 400, 3), dtype=np.uint8))
+    t = get_transform(type="clip", keep_ratio=False, image_size=224)(img)
+    assert t.shape == (3, 224, 224) and t.dtype == torch.float32
+    ref = torch.from_numpy(np.asarray(img.resize((224, 224), resample=2))).permute(2, 0, 1).float() / 255
+    ref = (ref - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
+    assert torch.allclose(t, ref, atol=1e-6)
