@@ -44,6 +44,8 @@ int seedmi_version(void);
 const char* seedmi_last_error(void);
 /* 0 if the current device is a gfx950 (MI355X); SEEDMI_E_ARCH otherwise. */
 int seedmi_check_device(void);
+/* Tuning knobs (process wide). "gemm": 0 = automatic kernel choice, 128 / 256 = force that tile kernel. */
+int seedmi_set_option(const char* key, int value);
 
 /* ---- GEMM epilogues ------------------------------------------------------------------------------------------ */
 #define SEEDMI_EPI_NONE 0          /* C = A W^T                                                                   */

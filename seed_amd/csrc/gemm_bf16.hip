@@ -18,8 +18,13 @@
 //
 // Workgroups are remapped so that each XCD (private 4 MiB L2) walks a contiguous range of tiles in
 // grouped (8 m-tiles x all n-tiles) order.
+#include <string.h>
 #include "common.h"
 #include "seedmi_internal.h"
+
+#ifndef SEEDMI_GEMM256_DEFAULT
+#define SEEDMI_GEMM256_DEFAULT 0
+#endif
 
 namespace {
 
@@ -47,94 +52,10 @@ SEEDMI_DEVINL void glds16(const bf16_t* gptr, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 15, g = lane >> 4;
 
-    // ---- workgroup -> tile (XCD-contiguous, grouped order)
-    int tm, tn;
-    {
-        const int nt = p.tiles_m * p.tiles_n;
-        const int bid = blockIdx.x;
-        const int q = nt >> 3, r = nt & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int gsize = GROUP_M * p.tiles_n;
-        const int gid = t / gsize;
-        const int first_m = gid * GROUP_M;
-        const int gm = min(p.tiles_m - first_m, GROUP_M);
-        const int in_g = t - gid * gsize;
-        tm = first_m + in_g % gm;
-        tn = in_g / gm;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- staging addresses: wave w copies rows [32w, 32w+32) of both tiles, 4 LDS-DMA pieces of 8 rows each
-    int offA[4], offW[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 32 * wave + 8 * j + (lane >> 3);
-        const int cs = lane & 7;                                  // chunk slot this lane fills in LDS
-        const int ra = min(m0 + row, p.M - 1);
-        const int rw = min(n0 + row, p.N - 1);
-        offA[j] = ra * p.lda + 8 * (cs ^ swzA(row));
-        offW[j] = rw * p.ldw + 8 * (cs ^ swzW(row));
-    }
-    // ---- fragment read addresses (byte offsets inside a stage), k-step 0; k-step 1 = ^64
-    int rdA[4], rdW[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ra = 64 * wm + 16 * t + li;                     // activation row feeding MFMA column li
-        rdA[t] = ra * 128 + ((g ^ swzA(ra)) << 4);
-        const int rw = 64 * wn + 16 * (li >> 2) + 4 * t + (li & 3);   // weight row feeding MFMA row li
-        rdW[t] = TILE_BYTES + rw * 128 + ((g ^ swzW(rw)) << 4);
-    }
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    auto stage = [&](int s, int kt) {
-        char* base = smem + s * STAGE_BYTES + wave * 4096;
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(p.A + (size_t)(offA[j] + k0), base + j * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(p.W + (size_t)(offW[j] + k0), base + TILE_BYTES + j * 1024);
-    };
-
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sb = smem + cur * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[4], w[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = *(const bf16x8*)(sb + (rdA[t] ^ (ks << 6)));
-#pragma unroll
-            for (int t = 0; t < 4; ++t) w[t] = *(const bf16x8*)(sb + (rdW[t] ^ (ks << 6)));
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane owns rows m = m0+64wm+16mi+li (mi=0..3), columns nb..nb+15
-    const int nb = n0 + 64 * wn + 16 * g;
+// ---- shared epilogue: the lane owns rows mrow0 + 16*mi + li (mi < MT) and the 16 contiguous columns nb..nb+15
+template <int EPI, int MT>
+SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int mrow0, int nb, int li) {
     if (nb >= p.N) return;
     const bool full = (nb + 16 <= p.N);
     float bias[16];
@@ -152,8 +73,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
         }
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + 64 * wm + 16 * mi + li;
+    for (int mi = 0; mi < MT; ++mi) {
+        const int m = mrow0 + 16 * mi + li;
         if (m >= p.M) continue;
         float v[16];
 #pragma unroll
@@ -218,6 +139,294 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
     }
 }
 
+// XCD-contiguous, grouped (GROUP_M m-tiles x all n-tiles) workgroup -> tile map
+SEEDMI_DEVINL void tile_of_block(const GemmParams& p, int& tm, int& tn) {
+    const int nt = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nt >> 3, r = nt & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int gsize = GROUP_M * p.tiles_n;
+    const int gid = t / gsize;
+    const int first_m = gid * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int in_g = t - gid * gsize;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, g = lane >> 4;
+
+    int tm, tn;
+    tile_of_block(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses: wave w copies rows [32w, 32w+32) of both tiles, 4 LDS-DMA pieces of 8 rows each
+    int offA[4], offW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 32 * wave + 8 * j + (lane >> 3);
+        const int cs = lane & 7;                                  // chunk slot this lane fills in LDS
+        const int ra = min(m0 + row, p.M - 1);
+        const int rw = min(n0 + row, p.N - 1);
+        offA[j] = ra * p.lda + 8 * (cs ^ swzA(row));
+        offW[j] = rw * p.ldw + 8 * (cs ^ swzW(row));
+    }
+    // ---- fragment read addresses (byte offsets inside a stage), k-step 0; k-step 1 = ^64
+    int rdA[4], rdW[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ra = 64 * wm + 16 * t + li;                     // activation row feeding MFMA column li
+        rdA[t] = ra * 128 + ((g ^ swzA(ra)) << 4);
+        const int rw = 64 * wn + 16 * (li >> 2) + 4 * t + (li & 3);   // weight row feeding MFMA row li
+        rdW[t] = TILE_BYTES + rw * 128 + ((g ^ swzW(rw)) << 4);
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    auto stage = [&](int s, int kt) {
+        char* base = smem + s * STAGE_BYTES + wave * 4096;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(p.A + (size_t)(offA[j] + k0), base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(p.W + (size_t)(offW[j] + k0), base + TILE_BYTES + j * 1024);
+    };
+
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = *(const bf16x8*)(sb + (rdA[t] ^ (ks << 6)));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = *(const bf16x8*)(sb + (rdW[t] ^ (ks << 6)));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    gemm_epilogue<EPI, 4>(p, acc, m0 + 64 * wm, n0 + 64 * wn + 16 * g, li);
+}
+
+
+// ======================================================================================================
+// Kernel "gemm256": 256x256x64 block tile, 8 waves (2 along M x 4 along N), 128x64 per wave.
+//
+// Deep-pipelined schedule for one workgroup per CU (128 KiB LDS, 2 waves per SIMD):
+//  * LDS holds two K-tiles (parity = kt & 1), each as four 16 KiB half-tiles A0|A1|W0|W1 (128 rows x 64 k,
+//    same XOR-swizzled 128-B rows as gemm128).  A wave only ever reads A_{wm} and W_{wn>>1}.
+//  * a K-tile is computed in 4 phases of 16 MFMAs (64x32 quadrants): P1 (mh0,nh0) P2 (mh0,nh1) P3 (mh1,nh1)
+//    P4 (mh1,nh0); fragments are read in the phase's LOAD section: P1 W(nh0)+A(mh0), P2 W(nh1), P3 A(mh1).
+//  * the two wave groups (wm = 0 / 1, one wave of each per SIMD) run one barrier apart: while one group is in
+//    its MFMA section the other issues its LDS reads and LDS-DMA, so the matrix pipe and the LDS/TA alternate
+//    owners instead of idling together.  Every phase is  LOAD | s_barrier | MFMA | s_barrier.
+//  * LDS-DMA is issued two half-tiles at a time, far ahead: A(kt+1) in P1 (slots last read in P3 of kt-1),
+//    W(kt+2) in P4 (slots last read in P2 of kt); one s_waitcnt vmcnt(0) per K-tile, in P4 *before* the new
+//    issue, retires loads that have been in flight for 3-4 phases.  Hazard rules (derived for the one-barrier
+//    stagger): a slot is read no earlier than the phase after the wait that retires it, and restaged no earlier
+//    than two phases after its last read.
+// Raw s_barrier (not __syncthreads) so LDS-DMA stays in flight across barriers; waits are explicit.
+constexpr int B2 = 256;
+constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
+constexpr int KT_BYTES = 4 * HALF_BYTES;          // 64 KiB per K-tile
+
+#define SEEDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, g = lane >> 4;
+
+    int tm, tn;
+    tile_of_block(p, tm, tn);
+    const int m0 = tm * B2, n0 = tn * B2;
+
+    // ---- LDS-DMA sources: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
+    int offA[2][2], offW[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
+            const int cs = lane & 7;
+            offA[h][j] = min(m0 + row, p.M - 1) * p.lda + 8 * (cs ^ swzA(row));
+            offW[h][j] = min(n0 + row, p.N - 1) * p.ldw + 8 * (cs ^ swzW(row));
+        }
+    // ---- fragment read bases (byte offsets inside a K-tile buffer); tile index adds an immediate
+    //   A: row = 16*mi + li inside half wm   (swizzle depends on li only)
+    //   W: row = 64*wn + 16*(li>>2) + 4*ni + (li&3) inside the 256-row tile, half wn>>1 (swizzle independent of ni)
+    const int rowW0 = 64 * wn + 16 * (li >> 2) + (li & 3);
+    const int rdA0 = wm * HALF_BYTES + li * 128 + ((g ^ swzA(li)) << 4);
+    const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((g ^ swzW(rowW0)) << 4);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
+        char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(p.A + (size_t)(offA[h][j] + k0), base + h * HALF_BYTES + j * 1024);
+    };
+    auto stageW = [&](int kt) {
+        char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(p.W + (size_t)(offW[h][j] + k0), base + h * HALF_BYTES + j * 1024);
+    };
+
+    // ---- prologue: K-tile 0 complete, W(1) already in flight
+    stageA(0);
+    stageW(0);
+    if (nk > 1) {
+        stageW(1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
+    SEEDMI_SCHED_FENCE();
+
+    bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh) k0/k1 x 4 tiles ; W(nh0), W(nh1): k0/k1 x 2 tiles
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + (kt & 1) * KT_BYTES;
+        const char* pa0 = sb + rdA0;                    // k-step 0
+        const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
+        const char* pw0 = sb + rdW0;
+        const char* pw1 = sb + (rdW0 ^ 64);
+
+        // ================= P1: (mh0, nh0) =================
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(pw0 + t * 512); fw0[2 + t] = *(const bf16x8*)(pw1 + t * 512); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
+        if (kt + 1 < nk) stageA(kt + 1);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+
+        // ================= P2: (mh0, nh1) =================
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { fw1[t] = *(const bf16x8*)(pw0 + (2 + t) * 512); fw1[2 + t] = *(const bf16x8*)(pw1 + (2 + t) * 512); }
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+
+        // ================= P3: (mh1, nh1) =================
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+
+        // ================= P4: (mh1, nh0) =================
+        // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 2 < nk) stageW(kt + 2);               // W slots of this parity were last read in P2
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
+
+    gemm_epilogue<EPI, 8>(p, acc, m0 + 128 * wm, n0 + 64 * wn + 16 * g, li);
+}
+
+template <int EPI>
+int launch_gemm256(GemmParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES);
+        attr_set = true;
+    }
+    p.tiles_m = (p.M + B2 - 1) / B2;
+    p.tiles_n = (p.N + B2 - 1) / B2;
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * KT_BYTES, stream, p);
+    return seedmi_check_launch("gemm256");
+}
+
 template <int EPI>
 int launch_gemm128(const GemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
@@ -230,7 +439,25 @@ int launch_gemm128(const GemmParams& p, hipStream_t stream) {
     return seedmi_check_launch("gemm128");
 }
 
+int g_gemm_variant = 0;      // 0 = auto, 128 / 256 = force a kernel (seedmi_set_option("gemm", v))
+
+template <int EPI>
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    const bool big = p.M >= 1024 && p.N >= 256;
+    const bool use256 = g_gemm_variant == 256 || (g_gemm_variant == 0 && big && SEEDMI_GEMM256_DEFAULT);
+    return use256 ? launch_gemm256<EPI>(p, s) : launch_gemm128<EPI>(p, s);
+}
+
 }  // namespace
+
+extern "C" int seedmi_set_option(const char* key, int value) {
+    if (key && !strcmp(key, "gemm") && (value == 0 || value == 128 || value == 256)) {
+        g_gemm_variant = value;
+        return SEEDMI_OK;
+    }
+    seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);
+    return SEEDMI_E_SHAPE;
+}
 
 extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
                                 const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group,
@@ -265,13 +492,13 @@ extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, con
     p.row_extra = row_extra;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
-        case EPI_NONE: return launch_gemm128<EPI_NONE>(p, s);
-        case EPI_BIAS: return launch_gemm128<EPI_BIAS>(p, s);
-        case EPI_BIAS_GELU: return launch_gemm128<EPI_BIAS_GELU>(p, s);
-        case EPI_BIAS_RESIDUAL: return launch_gemm128<EPI_BIAS_RESIDUAL>(p, s);
-        case EPI_BIAS_TANH: return launch_gemm128<EPI_BIAS_TANH>(p, s);
-        case EPI_SWIGLU: return launch_gemm128<EPI_SWIGLU>(p, s);
-        case EPI_PATCH_EMBED: return launch_gemm128<EPI_PATCH_EMBED>(p, s);
+        case EPI_NONE: return launch_gemm<EPI_NONE>(p, s);
+        case EPI_BIAS: return launch_gemm<EPI_BIAS>(p, s);
+        case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(p, s);
+        case EPI_BIAS_RESIDUAL: return launch_gemm<EPI_BIAS_RESIDUAL>(p, s);
+        case EPI_BIAS_TANH: return launch_gemm<EPI_BIAS_TANH>(p, s);
+        case EPI_SWIGLU: return launch_gemm<EPI_SWIGLU>(p, s);
+        case EPI_PATCH_EMBED: return launch_gemm<EPI_PATCH_EMBED>(p, s);
         default:
             seedmi_set_error("seedmi_gemm_bf16: unknown epilogue %d", epilogue);
             return SEEDMI_E_SHAPE;

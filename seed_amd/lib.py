@@ -56,6 +56,7 @@ SIGNATURES = {
     "seedmi_version": (_i, []),
     "seedmi_last_error": (C.c_char_p, []),
     "seedmi_check_device": (_i, []),
+    "seedmi_set_option": (_i, [C.c_char_p, _i]),
     "seedmi_gemm_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "seedmi_layernorm_bf16": (_i, [_vp, _i, _vp, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
     "seedmi_rmsnorm_bf16": (_i, [_vp, _i, _vp, C.c_float, _vp, _i, _i, _i, _vp]),

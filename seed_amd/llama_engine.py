@@ -34,6 +34,8 @@ class LlamaEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.SeedmiError("LlamaEngine needs a HIP device (cuda:N); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if cfg.head_dim != 128:
             raise L.SeedmiError(f"head_dim {cfg.head_dim}: the attention kernels are built for 128")
         with torch.cuda.device(self.device):

@@ -34,6 +34,8 @@ class TokenizerEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.SeedmiError("TokenizerEngine needs a HIP device (cuda:N); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(self.device):
             L.check(self.lib.seedmi_check_device(), "seedmi_check_device")
         self._keep = []          # tensors owning the device memory referenced by the C structs
