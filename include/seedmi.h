@@ -44,7 +44,8 @@ int seedmi_version(void);
 const char* seedmi_last_error(void);
 /* 0 if the current device is a gfx950 (MI355X); SEEDMI_E_ARCH otherwise. */
 int seedmi_check_device(void);
-/* Tuning knobs (process wide). "gemm": 0 = automatic kernel choice, 128 / 256 = force that tile kernel. */
+/* Tuning knobs (process wide). "gemm": 0 = automatic kernel choice, 128 / 256 = force that tile kernel;
+ * "tokenize_streams": 1 | 2 sub-batches run concurrently inside seedmi_tokenize (default 2 for batch >= 32). */
 int seedmi_set_option(const char* key, int value);
 
 /* ---- GEMM epilogues ------------------------------------------------------------------------------------------ */

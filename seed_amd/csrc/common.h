@@ -29,7 +29,20 @@ SEEDMI_DEVINL float rbf(float f) { return bf2f(f2bf(f)); }
 SEEDMI_DEVINL float lo_bf(uint32_t u) { return __uint_as_float(u << 16); }
 SEEDMI_DEVINL float hi_bf(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-SEEDMI_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-erf GELU (nn.GELU(), ACT2FN['gelu']).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-level)
+// evaluated on |z| so that 1+erf(z) for z < 0 is formed without cancellation: ~14 VALU + v_exp + v_rcp instead of the
+// ~40-instruction libm erff — the GEMM epilogue applies it to 128 values per lane and was 15 % of an fc1 tile.
+SEEDMI_DEVINL float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_z = p * t * __expf(-z * z);              // 1 - erf(|z|)
+    const float one_plus_erf = x >= 0.f ? 2.0f - erfc_z : erfc_z;
+    return 0.5f * x * one_plus_erf;
+}
 SEEDMI_DEVINL float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 SEEDMI_DEVINL float wave_sum(float v) {

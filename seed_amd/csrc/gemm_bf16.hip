@@ -23,7 +23,7 @@
 #include "seedmi_internal.h"
 
 #ifndef SEEDMI_GEMM256_DEFAULT
-#define SEEDMI_GEMM256_DEFAULT 0
+#define SEEDMI_GEMM256_DEFAULT 1
 #endif
 
 namespace {
@@ -455,6 +455,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
+    if (key && !strcmp(key, "tokenize_streams") && seedmi_tokenizer_set_streams(value) == SEEDMI_OK) return SEEDMI_OK;
     seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);
     return SEEDMI_E_SHAPE;
 }

@@ -24,13 +24,16 @@ struct SkinnyParams {
     bf16_t* C; int ldc;
 };
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyParams p) {
-    __shared__ float red[3][MT][64][4];
+// NW waves split K; every wave keeps two register sets of U k-steps in flight (the next batch is requested before
+// the current one is consumed), i.e. up to 2*U*(1+MT) 16-byte loads per lane outstanding — what a one-workgroup-per-CU
+// launch (N/16 = 256 workgroups for the 4096-row projections) needs to cover HBM latency.
+template <int MT, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
+    __shared__ float red[NW - 1][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
-    const int kslice = p.K >> 2;
+    const int kslice = p.K / NW;
     const int kbeg = wave * kslice;
     const int wrow = min(n0 + li, p.N - 1);
     const bf16_t* wp = p.W + (size_t)wrow * p.ldw + kbeg + 8 * g;
@@ -42,25 +45,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int U = 4;                                         // k-steps in flight per wave
-    for (int k = 0; k < kslice; k += 32 * U) {
-        bf16x8 wf[U], af[U][MT];
+    constexpr int U = 4;
+    bf16x8 w0[U], a0[U][MT], w1[U], a1[U][MT];
+    const int nb = (kslice + 32 * U - 1) / (32 * U);
+    auto load = [&](bf16x8 (&wf)[U], bf16x8 (&af)[U][MT], int b) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kk = k + 32 * u;
-            if (kk < kslice) {
-                wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + kk));
+            const int kk = min(32 * (U * b + u), kslice - 32);          // clamped: out-of-range steps are skipped below
+            wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + kk));
 #pragma unroll
-                for (int t = 0; t < MT; ++t) af[u][t] = *(const bf16x8*)(ap[t] + kk);
-            }
+            for (int t = 0; t < MT; ++t) af[u][t] = *(const bf16x8*)(ap[t] + kk);
         }
+    };
+    auto compute = [&](bf16x8 (&wf)[U], bf16x8 (&af)[U][MT], int b) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (k + 32 * u < kslice) {
+            if (32 * (U * b + u) < kslice) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[u][t], acc[t], 0, 0, 0);
             }
         }
+    };
+    load(w0, a0, 0);
+    for (int b = 0; b < nb; b += 2) {
+        if (b + 1 < nb) load(w1, a1, b + 1);
+        compute(w0, a0, b);
+        if (b + 2 < nb) load(w0, a0, b + 2);
+        if (b + 1 < nb) compute(w1, a1, b + 1);
     }
     if (wave > 0) {
 #pragma unroll
@@ -73,46 +84,55 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = ((acc[t][r] + red[0][t][lane][r]) + red[1][t][lane][r]) + red[2][t][lane][r];
+        for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += red[w][t][lane][r];
         const int m = 16 * t + li;
-        const int nb = n0 + 4 * g;
-        if (m >= p.M || nb >= p.N) continue;
+        const int nb_ = n0 + 4 * g;
+        if (m >= p.M || nb_ >= p.N) continue;
         float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
         if (EPI == EPI_BIAS_RESIDUAL) {
-            const bf16_t* rp = p.R + (size_t)m * p.ldr + nb;
+            const bf16_t* rp = p.R + (size_t)m * p.ldr + nb_;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (nb + r < p.N) v[r] = rbf(v[r]) + bf2f(rp[r]);
+            for (int r = 0; r < 4; ++r) if (nb_ + r < p.N) v[r] = rbf(v[r]) + bf2f(rp[r]);
         }
         if (EPI == EPI_SWIGLU) {
-            bf16_t* cp = p.C + (size_t)m * p.ldc + (nb >> 1);
-            if (nb + 1 < p.N) cp[0] = f2bf(rbf(silu(rbf(v[0]))) * rbf(v[1]));
-            if (nb + 3 < p.N) cp[1] = f2bf(rbf(silu(rbf(v[2]))) * rbf(v[3]));
+            bf16_t* cp = p.C + (size_t)m * p.ldc + (nb_ >> 1);
+            if (nb_ + 1 < p.N) cp[0] = f2bf(rbf(silu(rbf(v[0]))) * rbf(v[1]));
+            if (nb_ + 3 < p.N) cp[1] = f2bf(rbf(silu(rbf(v[2]))) * rbf(v[3]));
         } else {
-            bf16_t* cp = p.C + (size_t)m * p.ldc + nb;
-            if (nb + 4 <= p.N && (p.ldc % 4) == 0) {
+            bf16_t* cp = p.C + (size_t)m * p.ldc + nb_;
+            if (nb_ + 4 <= p.N && (p.ldc % 4) == 0) {
                 uint2 w;
                 w.x = pack2bf(v[0], v[1]);
                 w.y = pack2bf(v[2], v[3]);
                 *(uint2*)cp = w;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (nb + r < p.N) cp[r] = f2bf(v[r]);
+                for (int r = 0; r < 4; ++r) if (nb_ + r < p.N) cp[r] = f2bf(v[r]);
             }
         }
     }
 }
 
-template <int EPI>
-int launch_skinny(const SkinnyParams& p, hipStream_t s) {
+template <int EPI, int NW>
+int launch_skinny_nw(const SkinnyParams& p, hipStream_t s) {
     const int grid = (p.N + 15) / 16;
     const int mt = (p.M + 15) / 16;
     switch (mt) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI>), dim3(grid), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI>), dim3(grid), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI>), dim3(grid), dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI>), dim3(grid), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, NW>), dim3(grid), dim3(64 * NW), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, NW>), dim3(grid), dim3(64 * NW), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, NW>), dim3(grid), dim3(64 * NW), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, NW>), dim3(grid), dim3(64 * NW), 0, s, p); break;
     }
     return seedmi_check_launch("gemm_skinny");
+}
+
+template <int EPI>
+int launch_skinny(const SkinnyParams& p, hipStream_t s) {
+    // 8-way K split when each slice still holds at least two 128-deep batches, else 4-way
+    if ((p.K % 256) == 0 && p.K >= 2048) return launch_skinny_nw<EPI, 8>(p, s);
+    return launch_skinny_nw<EPI, 4>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------ decode attention

@@ -12,3 +12,6 @@ enum {
     EPI_SWIGLU = 5,         // silu(gate) * up on interleaved rows (llama_xformer.py:186)
     EPI_PATCH_EMBED = 6,    // conv bias + pos_embed, rows shifted past each image's cls slot (eva_vit.py:229,373-377)
 };
+
+// seedmi_set_option("tokenize_streams", 1|2): sub-batch overlap inside seedmi_tokenize (tokenizer.hip)
+int seedmi_tokenizer_set_streams(int n);

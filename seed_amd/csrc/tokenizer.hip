@@ -4,7 +4,12 @@
 //   Blip2QformerQuantizer.get_codebook_indices   models/seed_qformer/qformer_quantizer.py:288-307
 //   VisionTransformer.forward_features            models/seed_qformer/eva_vit.py:369-385
 //   BertModel.forward / BertLayer.forward         models/seed_qformer/qformer_causual.py:769-931, 359-444
-// Everything is enqueued on one stream; no allocation, no host sync, so the call is hipGraph-capturable.
+//
+// The batch is a pure map over images, so large batches are split into two sub-batches that run the same kernel
+// sequence on two HIP streams (fork/join with events on the caller's stream).  With one 128 KiB-LDS GEMM workgroup
+// per CU a single stream leaves the chip partly idle in every kernel's last round of tiles and during the
+// HBM-bound LayerNorm / attention kernels; the second stream's workgroups fill those holes.  Nothing is allocated
+// per call (streams/events are created once), there is no host sync, and fork/join by events is graph-capturable.
 #include "common.h"
 #include "../../include/seedmi.h"
 
@@ -49,54 +54,59 @@ TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
     return t;
 }
 
-#define CK(call)                  \
-    do {                          \
-        const int rc_ = (call);   \
+#define CK(call)                          \
+    do {                                  \
+        const int rc_ = (call);           \
         if (rc_ != SEEDMI_OK) return rc_; \
     } while (0)
+#define HIPCK(call)                                                                  \
+    do {                                                                             \
+        const hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) {                                                      \
+            seedmi_set_error("seedmi_tokenize: %s: %s", #call, hipGetErrorString(e_)); \
+            return SEEDMI_E_HIP;                                                     \
+        }                                                                            \
+    } while (0)
 
-}  // namespace
+// One sub-batch: its slice of the inputs/outputs, its own workspace, its stream.
+struct Part {
+    const seedmi_tokenizer_weights_t* w;
+    const char* images;
+    int images_fp32;
+    int B;
+    long long* ids;
+    seedmi_tokenizer_taps_t taps;      // already offset to this part's rows (null pointers stay null)
+    TokWs t;
+    hipStream_t s;
+};
 
-extern "C" size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int batch) {
-    if (!w || batch <= 0) return 0;
-    return carve(w, batch, nullptr).bytes;
-}
+// phases: 0 = patch embed; 1..depth = ViT blocks; depth+1 = ln_vision + query expand; then Q-Former layers; last = head + VQ
+int n_phases(const seedmi_tokenizer_weights_t* w) { return 1 + w->vit_depth + 1 + w->qf_layers + 1; }
 
-extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch,
-                               void* ids_i64, const seedmi_tokenizer_taps_t* taps, void* workspace,
-                               size_t workspace_bytes, void* stream) {
-    if (!w || !images || !ids_i64 || batch <= 0) {
-        seedmi_set_error("seedmi_tokenize: null argument or batch=%d", batch);
-        return SEEDMI_E_SHAPE;
-    }
-    if (w->img_size % w->patch || w->vit_dim % w->vit_heads || w->qf_dim % w->qf_heads) {
-        seedmi_set_error("seedmi_tokenize: inconsistent dims (img %d / patch %d, D %d / heads %d, Q %d / heads %d)",
-                         w->img_size, w->patch, w->vit_dim, w->vit_heads, w->qf_dim, w->qf_heads);
-        return SEEDMI_E_SHAPE;
-    }
-    const TokWs t = carve(w, batch, workspace);
-    if (!workspace || workspace_bytes < t.bytes || ((uintptr_t)workspace & 255)) {
-        seedmi_set_error("seedmi_tokenize: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, t.bytes);
-        return SEEDMI_E_ALIGN;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    const int B = batch;
+int run_phase(const Part& p, int phase) {
+    const seedmi_tokenizer_weights_t* w = p.w;
+    const TokWs& t = p.t;
+    void* s = (void*)p.s;
+    const int B = p.B;
     const int grid = w->img_size / w->patch;
     const int P = grid * grid, NT = P + 1;
     const int M = B * NT, Mq = B * w->n_query;
     const int D = w->vit_dim, F = w->vit_ffn, H = w->vit_heads, hd = D / H;
     const int Q = w->qf_dim, FF = w->qf_ffn, QH = w->qf_heads, qhd = Q / QH;
+    const int nq = w->n_query;
 
-    // ---- patch embed: unfold -> GEMM(+conv bias, +pos_embed, rows shifted past the cls slot); cls rows
-    CK(seedmi_im2col_patch(images, images_fp32, t.col, B, 3, w->img_size, w->patch, w->kpad, s));
-    CK(seedmi_gemm_bf16(B * P, D, w->kpad, t.col, w->kpad, w->patch_w, w->kpad, w->patch_b, w->pos_embed, D,
-                        SEEDMI_EPI_PATCH_EMBED, t.x, D, P, 1, s));
-    CK(seedmi_fill_rows(t.x, D, NT, 0, B, w->cls_pos0, D, 1, D, s));
-
-    // ---- 39 x Block (eva_vit.py:199-202)
-    const float vit_scale = 1.0f / sqrtf((float)hd);
-    for (int l = 0; l < w->vit_depth; ++l) {
-        const seedmi_vit_layer_t& L = w->vit[l];
+    if (phase == 0) {
+        // patch embed: unfold -> GEMM(+conv bias, +pos_embed, rows shifted past the cls slot); cls rows
+        CK(seedmi_im2col_patch(p.images, p.images_fp32, t.col, B, 3, w->img_size, w->patch, w->kpad, s));
+        CK(seedmi_gemm_bf16(B * P, D, w->kpad, t.col, w->kpad, w->patch_w, w->kpad, w->patch_b, w->pos_embed, D,
+                            SEEDMI_EPI_PATCH_EMBED, t.x, D, P, 1, s));
+        CK(seedmi_fill_rows(t.x, D, NT, 0, B, w->cls_pos0, D, 1, D, s));
+        return SEEDMI_OK;
+    }
+    phase -= 1;
+    if (phase < w->vit_depth) {                                             // Block.forward (eva_vit.py:199-202)
+        const seedmi_vit_layer_t& L = w->vit[phase];
+        const float vit_scale = 1.0f / sqrtf((float)hd);
         CK(seedmi_layernorm_bf16(t.x, D, L.ln1_w, L.ln1_b, 1e-6f, t.xn, D, M, D, s));
         CK(seedmi_gemm_bf16(M, 3 * D, D, t.xn, D, L.qkv_w, D, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, 0, 0, s));
         CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
@@ -105,18 +115,20 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
         CK(seedmi_layernorm_bf16(t.x, D, L.ln2_w, L.ln2_b, 1e-6f, t.xn, D, M, D, s));
         CK(seedmi_gemm_bf16(M, F, D, t.xn, D, L.fc1_w, D, L.fc1_b, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, 0, 0, s));
         CK(seedmi_gemm_bf16(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, s));
+        return SEEDMI_OK;
     }
-    // ---- ln_vision (blip2.py:179-184) -> image_embeds in xn
-    CK(seedmi_layernorm_bf16(t.x, D, w->ln_vision_w, w->ln_vision_b, 1e-5f, t.xn, D, M, D, s));
-    if (taps && taps->image_embeds)
-        if (hipMemcpyAsync(taps->image_embeds, t.xn, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return SEEDMI_E_HIP;
-
-    // ---- Q-Former: queries = LayerNorm(query_tokens) expanded over the batch
-    CK(seedmi_fill_rows(t.qx, Q, w->n_query, 0, B, w->query_ln, Q, w->n_query, Q, s));
-    const float q_scale = 1.0f / sqrtf((float)qhd);
-    const int nq = w->n_query;
-    for (int l = 0; l < w->qf_layers; ++l) {
-        const seedmi_qf_layer_t& L = w->qf[l];
+    phase -= w->vit_depth;
+    if (phase == 0) {
+        // ln_vision (blip2.py:179-184) -> image_embeds in xn; queries = LayerNorm(query_tokens) expanded over the batch
+        CK(seedmi_layernorm_bf16(t.x, D, w->ln_vision_w, w->ln_vision_b, 1e-5f, t.xn, D, M, D, s));
+        if (p.taps.image_embeds) HIPCK(hipMemcpyAsync(p.taps.image_embeds, t.xn, (size_t)M * D * 2, hipMemcpyDeviceToDevice, p.s));
+        CK(seedmi_fill_rows(t.qx, Q, nq, 0, B, w->query_ln, Q, nq, Q, s));
+        return SEEDMI_OK;
+    }
+    phase -= 1;
+    if (phase < w->qf_layers) {                                             // BertLayer.forward (qformer_causual.py:359-434)
+        const seedmi_qf_layer_t& L = w->qf[phase];
+        const float q_scale = 1.0f / sqrtf((float)qhd);
         // causal self-attention on the 32 queries + BertSelfOutput
         CK(seedmi_gemm_bf16(Mq, 3 * Q, Q, t.qx, Q, L.qkv_w, Q, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qqkv, 3 * Q, 0, 0, s));
         CK(seedmi_attention_bf16(t.qqkv, 3 * Q, t.qqkv + Q, 3 * Q, t.qqkv + 2 * Q, 3 * Q, t.qa, Q, B, QH, qhd, nq, nq,
@@ -133,16 +145,116 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
         CK(seedmi_gemm_bf16(Mq, FF, Q, t.qx, Q, L.ffn_w1, Q, L.ffn_b1, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.qh, FF, 0, 0, s));
         CK(seedmi_gemm_bf16(Mq, Q, FF, t.qh, FF, L.ffn_w2, FF, L.ffn_b2, t.qx, Q, SEEDMI_EPI_BIAS_RESIDUAL, t.qt, Q, 0, 0, s));
         CK(seedmi_layernorm_bf16(t.qt, Q, L.ffn_ln_w, L.ffn_ln_b, 1e-12f, t.qx, Q, Mq, Q, s));
+        return SEEDMI_OK;
     }
-    if (taps && taps->qformer_out)
-        if (hipMemcpyAsync(taps->qformer_out, t.qx, (size_t)Mq * Q * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return SEEDMI_E_HIP;
-
-    // ---- encode_task_layer: Linear -> Tanh -> Linear (qformer_quantizer.py:219-223), then the VQ argmin
+    // encode_task_layer: Linear -> Tanh -> Linear (qformer_quantizer.py:219-223), then the VQ argmin
     const int cd = w->code_dim;
+    if (p.taps.qformer_out) HIPCK(hipMemcpyAsync(p.taps.qformer_out, t.qx, (size_t)Mq * Q * 2, hipMemcpyDeviceToDevice, p.s));
     CK(seedmi_gemm_bf16(Mq, Q, Q, t.qx, Q, w->head_w0, Q, w->head_b0, nullptr, 0, SEEDMI_EPI_BIAS_TANH, t.qa, Q, 0, 0, s));
     CK(seedmi_gemm_bf16(Mq, cd, Q, t.qa, Q, w->head_w1, Q, w->head_b1, nullptr, 0, SEEDMI_EPI_BIAS, t.z, cd, 0, 0, s));
-    if (taps && taps->z)
-        if (hipMemcpyAsync(taps->z, t.z, (size_t)Mq * cd * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return SEEDMI_E_HIP;
-    CK(seedmi_vq_argmin_bf16(t.z, cd, w->codebook, w->code_sqnorm, ids_i64, Mq, w->n_embed, cd, s));
+    if (p.taps.z) HIPCK(hipMemcpyAsync(p.taps.z, t.z, (size_t)Mq * cd * 2, hipMemcpyDeviceToDevice, p.s));
+    CK(seedmi_vq_argmin_bf16(t.z, cd, w->codebook, w->code_sqnorm, p.ids, Mq, w->n_embed, cd, s));
+    return SEEDMI_OK;
+}
+
+constexpr int SPLIT_MIN_BATCH = 32;      // below this the kernels are too small for a second stream to help
+int g_tok_streams = 2;                    // seedmi_set_option("tokenize_streams", 1|2)
+
+struct ForkJoin {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+};
+thread_local ForkJoin g_fj;
+
+int ensure_forkjoin() {
+    int dev = 0;
+    HIPCK(hipGetDevice(&dev));
+    if (g_fj.side && g_fj.device == dev) return SEEDMI_OK;
+    HIPCK(hipStreamCreateWithFlags(&g_fj.side, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&g_fj.fork, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&g_fj.join, hipEventDisableTiming));
+    g_fj.device = dev;
+    return SEEDMI_OK;
+}
+
+size_t total_ws(const seedmi_tokenizer_weights_t* w, int batch) {
+    if (g_tok_streams >= 2 && batch >= SPLIT_MIN_BATCH) {
+        const int b0 = (batch + 1) / 2;
+        return carve(w, b0, nullptr).bytes + carve(w, batch - b0, nullptr).bytes;
+    }
+    return carve(w, batch, nullptr).bytes;
+}
+
+}  // namespace
+
+int seedmi_tokenizer_set_streams(int n) {
+    if (n != 1 && n != 2) return SEEDMI_E_SHAPE;
+    g_tok_streams = n;
+    return SEEDMI_OK;
+}
+
+extern "C" size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int batch) {
+    if (!w || batch <= 0) return 0;
+    // sized for either mode so a later seedmi_set_option("tokenize_streams", ...) cannot under-allocate
+    const size_t one = carve(w, batch, nullptr).bytes;
+    const int b0 = (batch + 1) / 2;
+    const size_t two = batch >= 2 ? carve(w, b0, nullptr).bytes + carve(w, batch - b0, nullptr).bytes : one;
+    return one > two ? one : two;
+}
+
+extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch,
+                               void* ids_i64, const seedmi_tokenizer_taps_t* taps, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!w || !images || !ids_i64 || batch <= 0) {
+        seedmi_set_error("seedmi_tokenize: null argument or batch=%d", batch);
+        return SEEDMI_E_SHAPE;
+    }
+    if (w->img_size % w->patch || w->vit_dim % w->vit_heads || w->qf_dim % w->qf_heads) {
+        seedmi_set_error("seedmi_tokenize: inconsistent dims (img %d / patch %d, D %d / heads %d, Q %d / heads %d)",
+                         w->img_size, w->patch, w->vit_dim, w->vit_heads, w->qf_dim, w->qf_heads);
+        return SEEDMI_E_SHAPE;
+    }
+    const size_t need = total_ws(w, batch);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) {
+        seedmi_set_error("seedmi_tokenize: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
+        return SEEDMI_E_ALIGN;
+    }
+    const int grid = w->img_size / w->patch;
+    const size_t NT = (size_t)grid * grid + 1;
+    const size_t img_bytes = (size_t)3 * w->img_size * w->img_size * (images_fp32 ? 4 : 2);
+    const bool split = g_tok_streams >= 2 && batch >= SPLIT_MIN_BATCH;
+    const int nparts = split ? 2 : 1;
+    Part parts[2];
+    int b_begin = 0;
+    char* ws = (char*)workspace;
+    for (int i = 0; i < nparts; ++i) {
+        Part& p = parts[i];
+        p.w = w;
+        p.B = split ? (i == 0 ? (batch + 1) / 2 : batch - (batch + 1) / 2) : batch;
+        p.images = (const char*)images + (size_t)b_begin * img_bytes;
+        p.images_fp32 = images_fp32;
+        p.ids = (long long*)ids_i64 + (size_t)b_begin * w->n_query;
+        p.taps.image_embeds = (taps && taps->image_embeds) ? (char*)taps->image_embeds + (size_t)b_begin * NT * w->vit_dim * 2 : nullptr;
+        p.taps.qformer_out = (taps && taps->qformer_out) ? (char*)taps->qformer_out + (size_t)b_begin * w->n_query * w->qf_dim * 2 : nullptr;
+        p.taps.z = (taps && taps->z) ? (char*)taps->z + (size_t)b_begin * w->n_query * w->code_dim * 2 : nullptr;
+        p.t = carve(w, p.B, ws);
+        ws += p.t.bytes;
+        p.s = (hipStream_t)stream;
+        b_begin += p.B;
+    }
+    if (split) {
+        CK(ensure_forkjoin());
+        parts[1].s = g_fj.side;
+        HIPCK(hipEventRecord(g_fj.fork, (hipStream_t)stream));
+        HIPCK(hipStreamWaitEvent(g_fj.side, g_fj.fork, 0));
+    }
+    const int np = n_phases(w);
+    for (int ph = 0; ph < np; ++ph)
+        for (int i = 0; i < nparts; ++i) CK(run_phase(parts[i], ph));
+    if (split) {
+        HIPCK(hipEventRecord(g_fj.join, g_fj.side));
+        HIPCK(hipStreamWaitEvent((hipStream_t)stream, g_fj.join, 0));
+    }
     return SEEDMI_OK;
 }
