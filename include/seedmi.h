@@ -70,6 +70,10 @@ int seedmi_layernorm_bf16(const void* x, int ldx, const void* gamma, const void*
 /* LlamaRMSNorm.forward (llama_xformer.py:105-113). */
 int seedmi_rmsnorm_bf16(const void* x, int ldx, const void* gamma, float eps, void* out, int ldo, int rows, int cols,
                         void* stream);
+/* Same, writing the fragment-major activation layout consumed by seedmi_gemm_skinny_packed_bf16(a_packed = 1):
+ * element (m, k) at (((m>>4)*(cols>>5) + (k>>5))*64 + ((k>>3)&3)*16 + (m&15))*8 + (k&7); out holds ceil(rows/16)*16 rows. */
+int seedmi_rmsnorm_packed_bf16(const void* x, int ldx, const void* gamma, float eps, void* out_packed, int rows, int cols,
+                               void* stream);
 /* PatchEmbed unfold (eva_vit.py:222-229): img [B,chans,hw,hw] (fp32 or bf16) -> col [B*(hw/patch)^2, kpad] bf16,
  * k = (c, kh, kw), zero padded to kpad. */
 int seedmi_im2col_patch(const void* img, int img_is_fp32, void* col, int batch, int chans, int hw, int patch, int kpad,
@@ -103,10 +107,18 @@ int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, c
  * q [B*T, H*hd]; caches [B][H][tmax][hd] holding kv_len = past_len + T keys; causal (top-left aligned on the
  * last T positions) when T > 1. */
 int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k_cache, const void* v_cache, void* out, int ldo,
-                                int B, int T, int H, int hd, int tmax, int past_len, float scale, void* stream);
+                                int B, int T, int H, int hd, int tmax, int past_len, float scale, int out_packed,
+                                void* stream);
 /* Skinny GEMM for decode (M <= 64): same contract as seedmi_gemm_bf16 restricted to NONE/BIAS_RESIDUAL/SWIGLU. */
 int seedmi_gemm_skinny_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* residual,
                             int ldr, int epilogue, void* C, int ldc, void* stream);
+/* The same GEMM on fragment-major weights: tile (16 rows) x k-step (32) blocks of 1 KiB laid out in the MFMA operand's
+ * lane order, so every wave streams one contiguous region of HBM (row-major weights put the 16 rows of a load on the
+ * same channels: 2.3 vs > 4 TB/s).  Pack once per weight with seedmi_pack_skinny_weights. */
+size_t seedmi_pack_skinny_weights_bytes(int N, int K);
+int seedmi_pack_skinny_weights(const void* W, int ldw, int N, int K, void* out, void* stream);
+int seedmi_gemm_skinny_packed_bf16(int M, int N, int K, const void* A, int lda, const void* W_packed, const void* residual,
+                                   int ldr, int epilogue, void* C, int ldc, int a_packed, int c_packed, void* stream);
 
 /* ---- path level: SEED-2 tokenizer ------------------------------------------------------------------------------ */
 typedef struct {
@@ -167,6 +179,8 @@ typedef struct {
     const void *gate_up_w;           /* gate_proj/up_proj row-interleaved [2F,h]          */
     const void *down_w;              /* down_proj [h,F]                                   */
     void *k_cache, *v_cache;         /* [B][H][tmax][hd] bf16, caller owned               */
+    /* optional fragment-major copies for the decode (M <= 64) path; NULL = stream the row-major weights */
+    const void *qkv_wp, *o_wp, *gate_up_wp, *down_wp;
 } seedmi_llama_layer_t;
 
 typedef struct {
@@ -177,6 +191,7 @@ typedef struct {
     const void* norm_w;              /* model.norm                                        */
     const void* lm_head;             /* [vocab_pad, h] (rows >= vocab zero)               */
     const void *cos_t, *sin_t;       /* [max_pos, hd] bf16                                */
+    const void* lm_head_p;           /* optional fragment-major lm_head (vocab_pad rows)  */
 } seedmi_llama_weights_t;
 
 size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, int batch, int T);

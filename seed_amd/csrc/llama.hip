@@ -6,6 +6,7 @@
 //                                 prefill = causal, decode (T == 1) = all cached keys; scale 1/sqrt(128)
 //  seedmi_llama_forward           LlamaForCausalLM.forward / LlamaModel.forward / LlamaDecoderLayer.forward
 //                                 (llama_xformer.py:661-743, 496-627, 280-332)
+#include <string.h>
 #include "common.h"
 #include "seedmi_internal.h"
 #include "../../include/seedmi.h"
@@ -22,47 +23,69 @@ struct SkinnyParams {
     const bf16_t* W; int ldw;
     const bf16_t* R; int ldr;
     bf16_t* C; int ldc;
+    int a_packed, c_packed;      // activations / SWIGLU output in the fragment-major layout (see norm_misc.hip PACK)
 };
 
 // NW waves split K; every wave keeps two register sets of U k-steps in flight (the next batch is requested before
 // the current one is consumed), i.e. up to 2*U*(1+MT) 16-byte loads per lane outstanding — what a one-workgroup-per-CU
 // launch (N/16 = 256 workgroups for the 4096-row projections) needs to cover HBM latency.
-template <int MT, int EPI, int NW>
+template <int MT, int EPI, int NW, bool NT, bool PACKED, int R>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
-    __shared__ float red[NW - 1][MT][64][4];
+    // R weight row-tiles (16 rows each) per workgroup share every activation fragment: the activation loads (16 rows x 64 B
+    // gathers out of L2) cost more TA cycles than the weight stream itself, so R = 2 where N leaves enough workgroups.
+    __shared__ float red[NW - 1][R][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = tid >> 6;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16 * R;
     const int kslice = p.K / NW;
     const int kbeg = wave * kslice;
-    const int wrow = min(n0 + li, p.N - 1);
-    const bf16_t* wp = p.W + (size_t)wrow * p.ldw + kbeg + 8 * g;
+    // PACKED: fragment-major weights (seedmi_pack_skinny_weights): tile j, k-step s is one contiguous 1 KiB block holding
+    // lane l's 16 bytes at l*16, so a wave streams a contiguous region instead of 16 rows x 64 B at a power-of-two stride
+    // (which lands every row of a load on the same HBM channels).
+    const bf16_t* wp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int wrow = min(n0 + 16 * r + li, p.N - 1);
+        wp[r] = PACKED ? p.W + ((size_t)(blockIdx.x * R + r) * (p.K >> 5) + (kbeg >> 5)) * 512 + lane * 8
+                       : p.W + (size_t)wrow * p.ldw + kbeg + 8 * g;
+    }
+    constexpr int WSTEP = PACKED ? 16 : 1;                           // element stride multiplier per k (32 k -> 512 elements)
     const bf16_t* ap[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) ap[t] = p.A + (size_t)min(16 * t + li, p.M - 1) * p.lda + kbeg + 8 * g;
+    for (int t = 0; t < MT; ++t)
+        ap[t] = p.a_packed ? p.A + ((size_t)(t * (p.K >> 5) + (kbeg >> 5)) * 64 + lane) * 8
+                           : p.A + (size_t)min(16 * t + li, p.M - 1) * p.lda + kbeg + 8 * g;
+    const int astep = p.a_packed ? 16 : 1;
 
-    f32x4 acc[MT];
+    f32x4 acc[R][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int U = 4;
-    bf16x8 w0[U], a0[U][MT], w1[U], a1[U][MT];
+    constexpr int U = (R * MT > 4) ? 2 : 4;                          // k-steps per register set (bounded by the VGPR budget)
+    bf16x8 w0[U][R], a0[U][MT], w1[U][R], a1[U][MT];
     const int nb = (kslice + 32 * U - 1) / (32 * U);
-    auto load = [&](bf16x8 (&wf)[U], bf16x8 (&af)[U][MT], int b) {
+    auto load = [&](bf16x8 (&wf)[U][R], bf16x8 (&af)[U][MT], int b) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = min(32 * (U * b + u), kslice - 32);          // clamped: out-of-range steps are skipped below
-            wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + kk));
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[u][t] = *(const bf16x8*)(ap[t] + kk);
+            for (int r = 0; r < R; ++r)
+                wf[u][r] = NT ? __builtin_nontemporal_load((const bf16x8*)(wp[r] + kk * WSTEP)) : *(const bf16x8*)(wp[r] + kk * WSTEP);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[u][t] = *(const bf16x8*)(ap[t] + kk * astep);
         }
     };
-    auto compute = [&](bf16x8 (&wf)[U], bf16x8 (&af)[U][MT], int b) {
+    auto compute = [&](bf16x8 (&wf)[U][R], bf16x8 (&af)[U][MT], int b) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (32 * (U * b + u) < kslice) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[u][t], acc[t], 0, 0, 0);
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][r], af[u][t], acc[r][t], 0, 0, 0);
             }
         }
     };
@@ -75,29 +98,36 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
     }
     if (wave > 0) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave - 1][t][lane][r] = acc[t][r];
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave - 1][r][t][lane][e] = acc[r][t][e];
     }
     __syncthreads();
     if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
         for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] += red[w][t][lane][r];
+            for (int e = 0; e < 4; ++e) acc[r][t][e] += red[w][r][t][lane][e];
         const int m = 16 * t + li;
-        const int nb_ = n0 + 4 * g;
+        const int nb_ = n0 + 16 * r + 4 * g;
         if (m >= p.M || nb_ >= p.N) continue;
-        float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+        float v[4] = {acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]};
         if (EPI == EPI_BIAS_RESIDUAL) {
             const bf16_t* rp = p.R + (size_t)m * p.ldr + nb_;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (nb_ + r < p.N) v[r] = rbf(v[r]) + bf2f(rp[r]);
+            for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) v[e] = rbf(v[e]) + bf2f(rp[e]);
         }
         if (EPI == EPI_SWIGLU) {
-            bf16_t* cp = p.C + (size_t)m * p.ldc + (nb_ >> 1);
+            const int kc = nb_ >> 1;                                     // output column of the first (gate, up) pair
+            bf16_t* cp = p.c_packed
+                ? p.C + ((size_t)((m >> 4) * (p.N >> 6) + (kc >> 5)) * 64 + ((kc >> 3) & 3) * 16 + (m & 15)) * 8 + (kc & 7)
+                : p.C + (size_t)m * p.ldc + kc;
             if (nb_ + 1 < p.N) cp[0] = f2bf(rbf(silu(rbf(v[0]))) * rbf(v[1]));
             if (nb_ + 3 < p.N) cp[1] = f2bf(rbf(silu(rbf(v[2]))) * rbf(v[3]));
         } else {
@@ -109,30 +139,60 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
                 *(uint2*)cp = w;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (nb_ + r < p.N) cp[r] = f2bf(v[r]);
+                for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) cp[e] = f2bf(v[e]);
             }
         }
     }
 }
 
-template <int EPI, int NW>
-int launch_skinny_nw(const SkinnyParams& p, hipStream_t s) {
-    const int grid = (p.N + 15) / 16;
+int g_skinny_nt = 1, g_skinny_nw = 0;
+
+int g_skinny_r = 0;
+
+template <int EPI, int NW, bool NT, bool PACKED, int R>
+int launch_skinny_r(const SkinnyParams& p, hipStream_t s) {
+    const int grid = (p.N + 16 * R - 1) / (16 * R);
     const int mt = (p.M + 15) / 16;
     switch (mt) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, NW>), dim3(grid), dim3(64 * NW), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, NW>), dim3(grid), dim3(64 * NW), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, NW>), dim3(grid), dim3(64 * NW), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, NW>), dim3(grid), dim3(64 * NW), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, NW, NT, PACKED, R>), dim3(grid), dim3(64 * NW), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, NW, NT, PACKED, R>), dim3(grid), dim3(64 * NW), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, NW, NT, PACKED, R>), dim3(grid), dim3(64 * NW), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, NW, NT, PACKED, R>), dim3(grid), dim3(64 * NW), 0, s, p); break;
     }
     return seedmi_check_launch("gemm_skinny");
 }
 
-template <int EPI>
+template <int EPI, int NW, bool NT, bool PACKED>
+int launch_skinny_nw(const SkinnyParams& p, hipStream_t s) {
+    // two row-tiles per workgroup when that still leaves >= 2 workgroups per CU (and the packed tile count is even)
+    const int tiles = (p.N + 15) / 16;
+    const bool r2 = g_skinny_r == 2 || (g_skinny_r == 0 && tiles >= 1024);
+    if (r2 && (tiles % 2) == 0) return launch_skinny_r<EPI, NW, NT, PACKED, 2>(p, s);
+    return launch_skinny_r<EPI, NW, NT, PACKED, 1>(p, s);
+}
+
+template <int EPI, bool PACKED>
 int launch_skinny(const SkinnyParams& p, hipStream_t s) {
     // 8-way K split when each slice still holds at least two 128-deep batches, else 4-way
-    if ((p.K % 256) == 0 && p.K >= 2048) return launch_skinny_nw<EPI, 8>(p, s);
-    return launch_skinny_nw<EPI, 4>(p, s);
+    const bool w8 = g_skinny_nw == 8 || (g_skinny_nw == 0 && (p.K % 256) == 0 && p.K >= 2048);
+    if (w8 && (p.K % 256) == 0)
+        return g_skinny_nt ? launch_skinny_nw<EPI, 8, true, PACKED>(p, s) : launch_skinny_nw<EPI, 8, false, PACKED>(p, s);
+    return g_skinny_nt ? launch_skinny_nw<EPI, 4, true, PACKED>(p, s) : launch_skinny_nw<EPI, 4, false, PACKED>(p, s);
+}
+
+// W [N, K] row-major -> fragment-major [ceil(N/16)][K/32][64 lanes][8]; rows beyond N are zero
+__global__ void pack_skinny_kernel(const bf16_t* __restrict__ W, int ldw, int N, int K, bf16_t* __restrict__ out) {
+    const long long total = (long long)((N + 15) / 16) * (K / 32) * 64;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long long blk = idx >> 6;
+        const int s = (int)(blk % (K / 32));
+        const int j = (int)(blk / (K / 32));
+        const int row = 16 * j + (lane & 15), col = 32 * s + 8 * (lane >> 4);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < N) v = *(const uint4*)(W + (size_t)row * ldw + col);
+        *(uint4*)(out + idx * 8) = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ decode attention
@@ -142,7 +202,7 @@ constexpr int DEC_HD = 128;
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int ldq,
                                                           const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
                                                           bf16_t* __restrict__ out, int ldo, int H, int tmax, int kv_len,
-                                                          float scale) {
+                                                          float scale, int out_packed) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     float* sc = dsm;                                // [kv_len] scores -> probabilities
     float* part = dsm + ((kv_len + 3) & ~3);        // [16][128] partial outputs
@@ -204,7 +264,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         float a = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) a += part[s2 * DEC_HD + tid];
-        out[(size_t)b * ldo + h * DEC_HD + tid] = f2bf(a);
+        const int kcol = h * DEC_HD + tid;
+        const size_t off = out_packed
+            ? ((size_t)((b >> 4) * ((H * DEC_HD) >> 5) + (kcol >> 5)) * 64 + ((kcol >> 3) & 3) * 16 + (b & 15)) * 8 + (kcol & 7)
+            : (size_t)b * ldo + kcol;
+        out[off] = f2bf(a);
     }
 }
 
@@ -353,14 +417,15 @@ struct Carver {
 struct LlamaWs { bf16_t *x, *xn, *qkv, *q, *att, *act; size_t bytes; };
 LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     const size_t M = (size_t)B * T, h = w->hidden, F = w->ffn;
+    const size_t Mp = (M + 15) / 16 * 16;            // fragment-major buffers hold whole 16-row tiles
     Carver c(ws);
     LlamaWs t;
     t.x = (bf16_t*)c.take(M * h * 2);
-    t.xn = (bf16_t*)c.take(M * h * 2);
+    t.xn = (bf16_t*)c.take(Mp * h * 2);
     t.qkv = (bf16_t*)c.take(M * 3 * h * 2);
     t.q = (bf16_t*)c.take(M * h * 2);
-    t.att = (bf16_t*)c.take(M * h * 2);
-    t.act = (bf16_t*)c.take(M * F * 2);
+    t.att = (bf16_t*)c.take(Mp * h * 2);
+    t.act = (bf16_t*)c.take(Mp * F * 2);
     t.bytes = c.off;
     return t;
 }
@@ -372,23 +437,37 @@ LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     } while (0)
 
 // dispatch: decode-sized M goes to the weight-streaming kernel, everything else to the 128x128 MFMA GEMM
-int linear(int M, int N, int K, const void* A, int lda, const void* W, const void* R, int ldr, int epi, void* C, int ldc,
-           void* s) {
-    if (M <= 64 && (K % 128) == 0)
+int linear(int M, int N, int K, const void* A, int lda, const void* W, const void* Wp, const void* R, int ldr, int epi,
+           void* C, int ldc, void* s, int a_packed = 0, int c_packed = 0) {
+    if (M <= 64 && (K % 128) == 0) {
+        if (Wp) return seedmi_gemm_skinny_packed_bf16(M, N, K, A, lda, Wp, R, ldr, epi, C, ldc, a_packed, c_packed, s);
         return seedmi_gemm_skinny_bf16(M, N, K, A, lda, W, K, R, ldr, epi, C, ldc, s);
+    }
     return seedmi_gemm_bf16(M, N, K, A, lda, W, K, nullptr, R, ldr, epi, C, ldc, 0, 0, s);
 }
 
 }  // namespace
 
-extern "C" int seedmi_gemm_skinny_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw,
-                                       const void* residual, int ldr, int epilogue, void* C, int ldc, void* stream) {
+int seedmi_llama_set_option(const char* key, int value) {
+    if (!strcmp(key, "skinny_nt") && (value == 0 || value == 1)) { g_skinny_nt = value; return SEEDMI_OK; }
+    if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
+    if (!strcmp(key, "skinny_rows") && (value == 0 || value == 1 || value == 2)) { g_skinny_r = value; return SEEDMI_OK; }
+    return SEEDMI_E_SHAPE;
+}
+
+static int skinny_entry(bool packed, int M, int N, int K, const void* A, int lda, const void* W, int ldw,
+                        const void* residual, int ldr, int epilogue, void* C, int ldc, int a_packed, int c_packed,
+                        void* stream) {
+    if ((a_packed && (K % 32)) || (c_packed && (epilogue != EPI_SWIGLU || (N % 64)))) {
+        seedmi_set_error("seedmi_gemm_skinny: packed activations need K %% 32 == 0; packed output is SWIGLU-only with N %% 64 == 0");
+        return SEEDMI_E_SHAPE;
+    }
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || (K % 128)) {
-        seedmi_set_error("seedmi_gemm_skinny_bf16: M=%d (1..64) N=%d K=%d (multiple of 128)", M, N, K);
+        seedmi_set_error("seedmi_gemm_skinny: M=%d (1..64) N=%d K=%d (multiple of 128)", M, N, K);
         return SEEDMI_E_SHAPE;
     }
     if ((lda % 8) || (ldw % 8) || (((uintptr_t)A | (uintptr_t)W) & 15) || ((uintptr_t)C & 3)) {
-        seedmi_set_error("seedmi_gemm_skinny_bf16: A/W need 16-byte aligned rows");
+        seedmi_set_error("seedmi_gemm_skinny: A/W need 16-byte aligned rows");
         return SEEDMI_E_ALIGN;
     }
     SkinnyParams p;
@@ -397,22 +476,55 @@ extern "C" int seedmi_gemm_skinny_bf16(int M, int N, int K, const void* A, int l
     p.W = (const bf16_t*)W; p.ldw = ldw;
     p.R = (const bf16_t*)residual; p.ldr = ldr;
     p.C = (bf16_t*)C; p.ldc = ldc;
+    p.a_packed = a_packed; p.c_packed = c_packed;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
-        case EPI_NONE: return launch_skinny<EPI_NONE>(p, s);
+        case EPI_NONE: return packed ? launch_skinny<EPI_NONE, true>(p, s) : launch_skinny<EPI_NONE, false>(p, s);
         case EPI_BIAS_RESIDUAL:
-            if (!residual) { seedmi_set_error("seedmi_gemm_skinny_bf16: residual epilogue without residual"); return SEEDMI_E_SHAPE; }
-            return launch_skinny<EPI_BIAS_RESIDUAL>(p, s);
-        case EPI_SWIGLU: return launch_skinny<EPI_SWIGLU>(p, s);
+            if (!residual) { seedmi_set_error("seedmi_gemm_skinny: residual epilogue without residual"); return SEEDMI_E_SHAPE; }
+            return packed ? launch_skinny<EPI_BIAS_RESIDUAL, true>(p, s) : launch_skinny<EPI_BIAS_RESIDUAL, false>(p, s);
+        case EPI_SWIGLU: return packed ? launch_skinny<EPI_SWIGLU, true>(p, s) : launch_skinny<EPI_SWIGLU, false>(p, s);
         default:
-            seedmi_set_error("seedmi_gemm_skinny_bf16: unsupported epilogue %d", epilogue);
+            seedmi_set_error("seedmi_gemm_skinny: unsupported epilogue %d", epilogue);
             return SEEDMI_E_SHAPE;
     }
 }
 
+extern "C" int seedmi_gemm_skinny_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw,
+                                       const void* residual, int ldr, int epilogue, void* C, int ldc, void* stream) {
+    return skinny_entry(false, M, N, K, A, lda, W, ldw, residual, ldr, epilogue, C, ldc, 0, 0, stream);
+}
+
+extern "C" int seedmi_gemm_skinny_packed_bf16(int M, int N, int K, const void* A, int lda, const void* W_packed,
+                                              const void* residual, int ldr, int epilogue, void* C, int ldc, int a_packed,
+                                              int c_packed, void* stream) {
+    return skinny_entry(true, M, N, K, A, lda, W_packed, 8, residual, ldr, epilogue, C, ldc, a_packed, c_packed, stream);
+}
+
+extern "C" size_t seedmi_pack_skinny_weights_bytes(int N, int K) {
+    return (size_t)((N + 15) / 16) * 16 * (size_t)K * 2;
+}
+
+extern "C" int seedmi_pack_skinny_weights(const void* W, int ldw, int N, int K, void* out, void* stream) {
+    if (N <= 0 || K <= 0 || (K % 32) || (ldw % 8) || (((uintptr_t)W | (uintptr_t)out) & 15)) {
+        seedmi_set_error("seedmi_pack_skinny_weights: N=%d K=%d ldw=%d (K multiple of 32, 16-byte aligned)", N, K, ldw);
+        return SEEDMI_E_SHAPE;
+    }
+    const long long total = (long long)((N + 15) / 16) * (K / 32) * 64;
+    long long grid = (total + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(pack_skinny_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ldw, N, K,
+                       (bf16_t*)out);
+    return seedmi_check_launch("pack_skinny_weights");
+}
+
 extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k_cache, const void* v_cache, void* out,
                                            int ldo, int B, int T, int H, int hd, int tmax, int past_len, float scale,
-                                           void* stream) {
+                                           int out_packed, void* stream) {
+    if (out_packed && T != 1) {
+        seedmi_set_error("seedmi_llama_attention_bf16: packed output is a decode (T == 1) feature");
+        return SEEDMI_E_SHAPE;
+    }
     if (hd != DEC_HD || B <= 0 || T <= 0 || H <= 0 || past_len < 0 || past_len + T > tmax) {
         seedmi_set_error("seedmi_llama_attention_bf16: B=%d T=%d H=%d hd=%d (must be 128) past=%d tmax=%d", B, T, H, hd, past_len, tmax);
         return SEEDMI_E_SHAPE;
@@ -435,7 +547,7 @@ extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k
             attr_set = true;
         }
         hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(256), lds, s, (const bf16_t*)q, ldq, (const bf16_t*)k_cache,
-                           (const bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, kv_len, scale);
+                           (const bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, kv_len, scale, out_packed);
         return seedmi_check_launch("attn_decode");
     }
     const int qblocks = (T + 63) / 64;
@@ -470,25 +582,34 @@ extern "C" int seedmi_llama_forward(const seedmi_llama_weights_t* w, const void*
     const int M = batch * T;
     const float scale = 1.0f / sqrtf((float)hd);
     CK(seedmi_embed_rows(ids_i64, w->embed, h, t.x, h, M, h, w->vocab, stream));
+    // decode steps (T == 1, M <= 64) keep every GEMM operand in the fragment-major layout end to end:
+    // rmsnorm -> [QKV], attention -> [o_proj], rmsnorm -> [gate|up] -> SwiGLU -> [down]; the residual stream stays row-major
+    const bool pk = (T == 1 && M <= 64 && (h % 128) == 0 && (F % 128) == 0 && w->layer[0].qkv_wp && w->layer[0].o_wp &&
+                     w->layer[0].gate_up_wp && w->layer[0].down_wp);
     for (int l = 0; l < w->layers; ++l) {
         const seedmi_llama_layer_t& L = w->layer[l];
-        CK(seedmi_rmsnorm_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, h, M, h, stream));
-        CK(linear(M, 3 * h, h, t.xn, h, L.qkv_w, nullptr, 0, EPI_NONE, t.qkv, 3 * h, stream));
+        if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, M, h, stream));
+        else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, h, M, h, stream));
+        CK(linear(M, 3 * h, h, t.xn, h, L.qkv_w, L.qkv_wp, nullptr, 0, EPI_NONE, t.qkv, 3 * h, stream, pk, 0));
         CK(seedmi_rope_kv_append(t.qkv, 3 * h, pos_i64, w->cos_t, w->sin_t, t.q, h, L.k_cache, L.v_cache, batch, T, H, hd,
                                  w->tmax, past_len, stream));
-        CK(seedmi_llama_attention_bf16(t.q, h, L.k_cache, L.v_cache, t.att, h, batch, T, H, hd, w->tmax, past_len, scale, stream));
-        CK(linear(M, h, h, t.att, h, L.o_w, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream));
-        CK(seedmi_rmsnorm_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, h, M, h, stream));
-        CK(linear(M, 2 * F, h, t.xn, h, L.gate_up_w, nullptr, 0, EPI_SWIGLU, t.act, F, stream));
-        CK(linear(M, h, F, t.act, F, L.down_w, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream));
+        CK(seedmi_llama_attention_bf16(t.q, h, L.k_cache, L.v_cache, t.att, h, batch, T, H, hd, w->tmax, past_len, scale,
+                                       pk, stream));
+        CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
+        if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, M, h, stream));
+        else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, h, M, h, stream));
+        CK(linear(M, 2 * F, h, t.xn, h, L.gate_up_w, L.gate_up_wp, nullptr, 0, EPI_SWIGLU, t.act, F, stream, pk, pk));
+        CK(linear(M, h, F, t.act, F, L.down_w, L.down_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
     }
+    const bool pk_head = (batch <= 64 && (h % 128) == 0 && w->lm_head_p);
     if (last_only) {
         // final norm + lm_head on the last position of every sequence only (decode fast path)
-        CK(seedmi_rmsnorm_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, h, batch, h, stream));
-        CK(linear(batch, w->vocab, h, t.xn, h, w->lm_head, nullptr, 0, EPI_NONE, logits, ldl, stream));
+        if (pk_head) CK(seedmi_rmsnorm_packed_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, batch, h, stream));
+        else CK(seedmi_rmsnorm_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, h, batch, h, stream));
+        CK(linear(batch, w->vocab, h, t.xn, h, w->lm_head, w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream, pk_head, 0));
     } else {
         CK(seedmi_rmsnorm_bf16(t.x, h, w->norm_w, w->rms_eps, t.xn, h, M, h, stream));
-        CK(linear(M, w->vocab, h, t.xn, h, w->lm_head, nullptr, 0, EPI_NONE, logits, ldl, stream));
+        CK(linear(M, w->vocab, h, t.xn, h, w->lm_head, w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream));
     }
     return SEEDMI_OK;
 }

@@ -15,7 +15,10 @@ namespace {
 constexpr int NORM_WAVES = 4;
 
 // one wave per row; row held in registers as MAXC chunks of 8 bf16 per lane
-template <int MAXC, bool RMS>
+// PACK: write the row in the decode GEMM's fragment-major activation layout (16-row tile x 32-k step = 1 KiB block in MFMA
+// lane order) so the consumer's operand loads are contiguous: chunk c of row m goes to
+// (((m>>4)*(cols>>5) + (c>>2))*64 + (c&3)*16 + (m&15)) * 8 elements.
+template <int MAXC, bool RMS, bool PACK>
 __global__ __launch_bounds__(64 * NORM_WAVES) void norm_kernel(const bf16_t* __restrict__ x, int ldx,
                                                                const bf16_t* __restrict__ gamma,
                                                                const bf16_t* __restrict__ beta, float eps,
@@ -82,19 +85,24 @@ __global__ __launch_bounds__(64 * NORM_WAVES) void norm_kernel(const bf16_t* __r
                 }
                 ow[j] = pack2bf(a, b2);
             }
-            *(uint4*)(orow + 8 * c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            if (PACK) {
+                const size_t off = ((size_t)((row >> 4) * (cols >> 5) + (c >> 2)) * 64 + (c & 3) * 16 + (row & 15)) * 8;
+                *(uint4*)(out + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            } else {
+                *(uint4*)(orow + 8 * c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            }
         }
     }
 }
 
-template <bool RMS>
+template <bool RMS, bool PACK = false>
 int launch_norm(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* out, int ldo, int rows,
                 int cols, hipStream_t s) {
     const int grid = (rows + NORM_WAVES - 1) / NORM_WAVES;
     const int chunks = cols / 8;
 #define SEEDMI_NORM_CASE(MAXC_)                                                                                   \
     if (chunks <= 64 * MAXC_) {                                                                                   \
-        hipLaunchKernelGGL((norm_kernel<MAXC_, RMS>), dim3(grid), dim3(64 * NORM_WAVES), 0, s, (const bf16_t*)x, ldx, \
+        hipLaunchKernelGGL((norm_kernel<MAXC_, RMS, PACK>), dim3(grid), dim3(64 * NORM_WAVES), 0, s, (const bf16_t*)x, ldx, \
                            (const bf16_t*)gamma, (const bf16_t*)beta, eps, (bf16_t*)out, ldo, rows, cols);        \
         return seedmi_check_launch("norm");                                                                       \
     }
@@ -245,6 +253,15 @@ extern "C" int seedmi_rmsnorm_bf16(const void* x, int ldx, const void* gamma, fl
         return SEEDMI_E_SHAPE;
     }
     return launch_norm<true>(x, ldx, gamma, nullptr, eps, out, ldo, rows, cols, (hipStream_t)stream);
+}
+
+extern "C" int seedmi_rmsnorm_packed_bf16(const void* x, int ldx, const void* gamma, float eps, void* out_packed, int rows,
+                                          int cols, void* stream) {
+    if (rows <= 0 || cols <= 0 || (cols % 32) || (ldx % 8)) {
+        seedmi_set_error("seedmi_rmsnorm_packed_bf16: rows=%d cols=%d ldx=%d (cols multiple of 32)", rows, cols, ldx);
+        return SEEDMI_E_SHAPE;
+    }
+    return launch_norm<true, true>(x, ldx, gamma, nullptr, eps, out_packed, cols, rows, cols, (hipStream_t)stream);
 }
 
 extern "C" int seedmi_im2col_patch(const void* img, int img_is_fp32, void* col, int batch, int chans, int hw, int patch,

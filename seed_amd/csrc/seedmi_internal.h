@@ -15,3 +15,5 @@ enum {
 
 // seedmi_set_option("tokenize_streams", 1|2): sub-batch overlap inside seedmi_tokenize (tokenizer.hip)
 int seedmi_tokenizer_set_streams(int n);
+// seedmi_set_option("skinny_nt" | "skinny_waves", v): decode GEMM experiments (llama.hip)
+int seedmi_llama_set_option(const char* key, int value);

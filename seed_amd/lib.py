@@ -41,14 +41,15 @@ class TokenizerTaps(C.Structure):
 
 
 class LlamaLayer(C.Structure):
-    _fields_ = [(n, _vp) for n in ("ln1_w", "qkv_w", "o_w", "ln2_w", "gate_up_w", "down_w", "k_cache", "v_cache")]
+    _fields_ = [(n, _vp) for n in ("ln1_w", "qkv_w", "o_w", "ln2_w", "gate_up_w", "down_w", "k_cache", "v_cache",
+                                    "qkv_wp", "o_wp", "gate_up_wp", "down_wp")]
 
 
 class LlamaWeights(C.Structure):
     _fields_ = ([(n, _i) for n in ("hidden", "layers", "heads", "ffn", "vocab", "vocab_pad", "max_pos", "tmax",
                                    "batch_cap")] + [("rms_eps", C.c_float)] +
                 [("embed", _vp), ("layer", C.POINTER(LlamaLayer)), ("norm_w", _vp), ("lm_head", _vp),
-                 ("cos_t", _vp), ("sin_t", _vp)])
+                 ("cos_t", _vp), ("sin_t", _vp), ("lm_head_p", _vp)])
 
 
 # name -> (restype, argtypes); must list every symbol include/seedmi.h declares (tests check the export table)
@@ -67,8 +68,12 @@ SIGNATURES = {
     "seedmi_vq_argmin_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "seedmi_embed_rows": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "seedmi_llama_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _vp]),
+    "seedmi_llama_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
     "seedmi_gemm_skinny_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "seedmi_pack_skinny_weights_bytes": (C.c_size_t, [_i, _i]),
+    "seedmi_pack_skinny_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "seedmi_gemm_skinny_packed_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "seedmi_rmsnorm_packed_bf16": (_i, [_vp, _i, _vp, C.c_float, _vp, _i, _i, _vp]),
     "seedmi_tokenize_workspace_bytes": (C.c_size_t, [C.POINTER(TokenizerWeights), _i]),
     "seedmi_tokenize": (_i, [C.POINTER(TokenizerWeights), _vp, _i, _i, _vp, C.POINTER(TokenizerTaps), _vp,
                              C.c_size_t, _vp]),

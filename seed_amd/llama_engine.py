@@ -28,7 +28,7 @@ def _round_up(x, m):
 
 class LlamaEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: LlamaConfig, device="cuda", batch_cap: int = 32,
-                 tmax: Optional[int] = None):
+                 tmax: Optional[int] = None, decode_packed: bool = True):
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -41,6 +41,7 @@ class LlamaEngine:
         with torch.cuda.device(self.device):
             L.check(self.lib.seedmi_check_device(), "seedmi_check_device")
         self.batch_cap = batch_cap
+        self.decode_packed = decode_packed     # second, fragment-major copy of every weight for the M <= 64 path
         self.tmax = tmax or cfg.max_pos
         self.vocab_pad = _round_up(cfg.vocab, 16)
         self._keep = []
@@ -53,6 +54,17 @@ class LlamaEngine:
         t = t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
         self._keep.append(t)
         return t
+
+    def _packed(self, w: torch.Tensor):
+        """Fragment-major copy for the weight-streaming decode GEMM (288 GB of HBM: the 2x copy is cheap)."""
+        if not self.decode_packed:
+            return None
+        N, K = w.shape
+        out = torch.empty(self.lib.seedmi_pack_skinny_weights_bytes(N, K) // 2, dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.seedmi_pack_skinny_weights(L.ptr(w), K, N, K, L.ptr(out), L.stream_ptr()), "pack_skinny")
+        self._keep.append(out)
+        return out
 
     def _pack(self, sd):
         cfg = self.cfg
@@ -69,12 +81,16 @@ class LlamaEngine:
             pre = f"model.layers.{i}."
             l = layers[i]
             l.ln1_w = p(self._dev(sd[pre + "input_layernorm.weight"]))
-            l.qkv_w = p(self._dev(torch.cat([sd[pre + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)))
-            l.o_w = p(self._dev(sd[pre + "self_attn.o_proj.weight"]))
+            qkv = self._dev(torch.cat([sd[pre + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0))
+            o = self._dev(sd[pre + "self_attn.o_proj.weight"])
+            l.qkv_w, l.o_w = p(qkv), p(o)
+            l.qkv_wp, l.o_wp = p(self._packed(qkv)), p(self._packed(o))
             l.ln2_w = p(self._dev(sd[pre + "post_attention_layernorm.weight"]))
             gate, up = sd[pre + "mlp.gate_proj.weight"], sd[pre + "mlp.up_proj.weight"]
-            l.gate_up_w = p(self._dev(torch.stack((gate, up), dim=1).reshape(2 * F, h)))
-            l.down_w = p(self._dev(sd[pre + "mlp.down_proj.weight"]))
+            gu = self._dev(torch.stack((gate, up), dim=1).reshape(2 * F, h))
+            dn = self._dev(sd[pre + "mlp.down_proj.weight"])
+            l.gate_up_w, l.down_w = p(gu), p(dn)
+            l.gate_up_wp, l.down_wp = p(self._packed(gu)), p(self._packed(dn))
             kc = torch.zeros(self.batch_cap, cfg.heads, self.tmax, cfg.head_dim, dtype=torch.bfloat16, device=self.device)
             vc = torch.zeros_like(kc)
             self.k_cache.append(kc)
@@ -85,7 +101,9 @@ class LlamaEngine:
         w.norm_w = p(self._dev(sd["model.norm.weight"]))
         lm = torch.zeros(self.vocab_pad, h, dtype=torch.bfloat16)
         lm[:cfg.vocab] = sd["lm_head.weight"].to(torch.bfloat16).cpu()
-        w.lm_head = p(self._dev(lm))
+        lm = self._dev(lm)
+        w.lm_head = p(lm)
+        w.lm_head_p = p(self._packed(lm))
         # LlamaRotaryEmbedding.__init__ (llama_xformer.py:118-134)
         hd = cfg.head_dim
         inv_freq = 1.0 / (cfg.rope_base ** (torch.arange(0, hd, 2).float() / hd))

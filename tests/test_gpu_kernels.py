@@ -331,6 +331,15 @@ def test_gemm_skinny(lib, M, N, K, epi):
     L.check(rc, "gemm_skinny")
     torch.cuda.synchronize()
     assert_close_bf16(C[:, :ncol], want, f"gemm_skinny {M}x{N}x{K} {epi}", frac=0.998)
+    # fragment-major (packed) weights: same arithmetic in the same order -> bit-identical output
+    Wp = torch.empty(lib.seedmi_pack_skinny_weights_bytes(N, K) // 2, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.seedmi_pack_skinny_weights(L.ptr(W), K, N, K, L.ptr(Wp), L.stream_ptr()), "pack")
+    C2 = torch.zeros_like(C)
+    rc = lib.seedmi_gemm_skinny_packed_bf16(M, N, K, L.ptr(A), K, L.ptr(Wp), L.ptr(res), 0 if res is None else N, code,
+                                            L.ptr(C2), ldc, 0, 0, L.stream_ptr())
+    L.check(rc, "gemm_skinny_packed")
+    torch.cuda.synchronize()
+    assert torch.equal(C, C2), "packed-weight decode GEMM differs from the row-major one"
 
 
 def _rope_tables(max_pos, hd):
@@ -381,7 +390,7 @@ def test_rope_and_llama_attention(lib, B, T, H, past):
     out = torch.zeros(B * T, h, dtype=torch.bfloat16, device="cuda")
     scale = 1.0 / math.sqrt(hd)
     rc = lib.seedmi_llama_attention_bf16(L.ptr(q_out), h, L.ptr(kc), L.ptr(vc), L.ptr(out), h, B, T, H, hd, tmax, past, scale,
-                                         L.stream_ptr())
+                                         0, L.stream_ptr())
     L.check(rc, "llama_attention")
     torch.cuda.synchronize()
     kall = kc[:, :, :past + T].float()
