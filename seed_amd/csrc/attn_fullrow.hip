@@ -12,6 +12,7 @@
 // The S^T orientation makes P's accumulator layout *be* the next MFMA's operand layout: lane (i, g) holds
 // keys {16t + 4g + r}, and V^T fragments are read with the same (g, j) -> key mapping, so no cross-lane
 // movement or LDS round trip is needed for P.
+#include <string.h>
 #include "common.h"
 #include "seedmi_internal.h"
 
@@ -27,13 +28,15 @@ struct AttnParams {
 template <int HD> struct AttnGeom {
     static constexpr int HDP = (HD + 31) / 32 * 32;
     static constexpr int KPITCH = (HDP == 96) ? 120 : HDP + 8;     // elements; 16-B chunks per row odd
+    static constexpr int VRP = HDP + 16;                           // 224 B / 160 B / 288 B rows: ds_read_b64_tr_b16 conflict-free
 };
 
-template <int HD, int NKP, bool CAUSAL, bool ROUND_S>
+template <int HD, int NKP, bool CAUSAL, bool ROUND_S, bool TRV>
 __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
     constexpr int HDP = AttnGeom<HD>::HDP;
     constexpr int KPITCH = AttnGeom<HD>::KPITCH;
-    constexpr int VPITCH = NKP + 8;                                 // 8 * odd for NKP in {32, 288}
+    constexpr int VPITCH = NKP + 8;                                 // V^T image: 8 * odd for NKP in {32, 288}
+    constexpr int VRP = AttnGeom<HD>::VRP;                          // row-major V image (TRV): 32-byte * odd row pitch
     constexpr int NT = NKP / 16;                                    // key tiles
     constexpr int KS = HDP / 32;                                    // k-steps of QK^T
     constexpr int KK = NKP / 32;                                    // k-steps of PV
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ksm = (bf16_t*)smem;                                    // [NKP][KPITCH]
-    bf16_t* Vt = Ksm + NKP * KPITCH;                                // [HDP][VPITCH]
+    bf16_t* Vt = Ksm + NKP * KPITCH;                                // [HDP][VPITCH]  or, TRV, row-major [NKP][VRP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -59,21 +62,32 @@ __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
         if (row < p.nk && 8 * c < HD) v = *(const uint4*)(p.K + (krow0 + row) * p.ldk + hoff + 8 * c);
         *(uint4*)(Ksm + row * KPITCH + 8 * c) = v;
     }
-    // ---- stage V transposed: thread takes a key pair x 8 hd values, writes 8 packed dwords
-    for (int idx = tid; idx < (NKP / 2) * CH; idx += 512) {
-        const int c = idx / (NKP / 2), kp = idx - c * (NKP / 2);
-        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-        if (8 * c < HD) {
-            if (2 * kp < p.nk) v0 = *(const uint4*)(p.V + (krow0 + 2 * kp) * p.ldv + hoff + 8 * c);
-            if (2 * kp + 1 < p.nk) v1 = *(const uint4*)(p.V + (krow0 + 2 * kp + 1) * p.ldv + hoff + 8 * c);
+    if (TRV) {
+        // ---- stage V row-major exactly like K (coalesced 16-B loads, ds_write_b128); the PV operand is produced by the
+        //      hardware transpose read ds_read_b64_tr_b16, so no transposed image has to be built
+        for (int idx = tid; idx < NKP * CH; idx += 512) {
+            const int row = idx / CH, c = idx - row * CH;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < p.nk && 8 * c < HD) v = *(const uint4*)(p.V + (krow0 + row) * p.ldv + hoff + 8 * c);
+            *(uint4*)(Vt + row * VRP + 8 * c) = v;
         }
-        const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w};
-        const uint32_t d[4] = {v1.x, v1.y, v1.z, v1.w};
-        uint32_t* dst = (uint32_t*)(Vt + (8 * c) * VPITCH + 2 * kp);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dst[(2 * i) * (VPITCH / 2)] = (a[i] & 0xffffu) | (d[i] << 16);
-            dst[(2 * i + 1) * (VPITCH / 2)] = (a[i] >> 16) | (d[i] & 0xffff0000u);
+    } else {
+        // ---- stage V transposed: thread takes a key pair x 8 hd values, writes 8 packed dwords
+        for (int idx = tid; idx < (NKP / 2) * CH; idx += 512) {
+            const int c = idx / (NKP / 2), kp = idx - c * (NKP / 2);
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+            if (8 * c < HD) {
+                if (2 * kp < p.nk) v0 = *(const uint4*)(p.V + (krow0 + 2 * kp) * p.ldv + hoff + 8 * c);
+                if (2 * kp + 1 < p.nk) v1 = *(const uint4*)(p.V + (krow0 + 2 * kp + 1) * p.ldv + hoff + 8 * c);
+            }
+            const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w};
+            const uint32_t d[4] = {v1.x, v1.y, v1.z, v1.w};
+            uint32_t* dst = (uint32_t*)(Vt + (8 * c) * VPITCH + 2 * kp);
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dst[(2 * i) * (VPITCH / 2)] = (a[i] & 0xffffu) | (d[i] << 16);
+                dst[(2 * i + 1) * (VPITCH / 2)] = (a[i] >> 16) | (d[i] & 0xffff0000u);
+            }
         }
     }
     __syncthreads();
@@ -115,8 +129,10 @@ __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * t + 4 * g + r;
                 float v = ROUND_S ? rbf(s[t][r]) : s[t][r];
-                const bool dead = (key >= p.nk) || (CAUSAL && key > qrow);
-                v = dead ? -INFINITY : v;
+                if (CAUSAL || 16 * t + 15 >= p.nk) {                // wave-uniform: whole tiles of live keys skip the mask
+                    const bool dead = (key >= p.nk) || (CAUSAL && key > qrow);
+                    v = dead ? -INFINITY : v;
+                }
                 s[t][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -148,9 +164,21 @@ __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
             const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
             for (int n = 0; n < HT; ++n) {
-                const bf16_t* vp = Vt + (16 * n + li) * VPITCH + 32 * kk + 4 * g;
-                const uint2 lo = *(const uint2*)vp;
-                const uint2 hi = *(const uint2*)(vp + 16);
+                uint2 lo, hi;
+                if (TRV) {
+                    // 16-lane group g fetches the [4 keys x 16 cols] block of keys 32kk+4g.. (and +16): lane li supplies the
+                    // address of row li>>2, cols 4*(li&3)..+3 and receives column li of the block = keys (g, j) of col 16n+li
+                    typedef __attribute__((ext_vector_type(4))) short s16x4;
+                    const bf16_t* vp = Vt + (32 * kk + 4 * g + (li >> 2)) * VRP + 16 * n + 4 * (li & 3);
+                    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
+                    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 16 * VRP));
+                    lo = __builtin_bit_cast(uint2, a);
+                    hi = __builtin_bit_cast(uint2, b);
+                } else {
+                    const bf16_t* vp = Vt + (16 * n + li) * VPITCH + 32 * kk + 4 * g;
+                    lo = *(const uint2*)vp;
+                    hi = *(const uint2*)(vp + 16);
+                }
                 const uint4 vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[n], 0, 0, 0);
             }
@@ -173,21 +201,34 @@ __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
     }
 }
 
-template <int HD, int NKP, bool CAUSAL, bool ROUND_S>
-int launch_attn(const AttnParams& p, int batch, hipStream_t stream) {
+int g_attn_trv = 1;     // seedmi_set_option("attn_trv", 0|1): hardware transpose read for V (1) or transposed LDS image (0)
+
+template <int HD, int NKP, bool CAUSAL, bool ROUND_S, bool TRV>
+int launch_attn_v(const AttnParams& p, int batch, hipStream_t stream) {
     constexpr int HDP = AttnGeom<HD>::HDP;
-    constexpr int lds = (NKP * AttnGeom<HD>::KPITCH + HDP * (NKP + 8)) * 2;
+    constexpr int lds = (NKP * AttnGeom<HD>::KPITCH + (TRV ? NKP * AttnGeom<HD>::VRP : HDP * (NKP + 8))) * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_fullrow_kernel<HD, NKP, CAUSAL, ROUND_S>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_fullrow_kernel<HD, NKP, CAUSAL, ROUND_S, TRV>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_fullrow_kernel<HD, NKP, CAUSAL, ROUND_S>), dim3(batch * p.heads), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((attn_fullrow_kernel<HD, NKP, CAUSAL, ROUND_S, TRV>), dim3(batch * p.heads), dim3(512), lds, stream, p);
     return seedmi_check_launch("attn_fullrow");
 }
 
+template <int HD, int NKP, bool CAUSAL, bool ROUND_S>
+int launch_attn(const AttnParams& p, int batch, hipStream_t stream) {
+    return g_attn_trv ? launch_attn_v<HD, NKP, CAUSAL, ROUND_S, true>(p, batch, stream)
+                      : launch_attn_v<HD, NKP, CAUSAL, ROUND_S, false>(p, batch, stream);
+}
+
 }  // namespace
+
+int seedmi_attn_set_option(const char* key, int value) {
+    if (!strcmp(key, "attn_trv") && (value == 0 || value == 1)) { g_attn_trv = value; return SEEDMI_OK; }
+    return SEEDMI_E_SHAPE;
+}
 
 // Q/K/V/O are [batch*n, ld] bf16 matrices whose columns [h*hd, (h+1)*hd) belong to head h.
 extern "C" int seedmi_attention_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,

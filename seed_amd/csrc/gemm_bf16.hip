@@ -248,11 +248,38 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 //    stagger): a slot is read no earlier than the phase after the wait that retires it, and restaged no earlier
 //    than two phases after its last read.
 // Raw s_barrier (not __syncthreads) so LDS-DMA stays in flight across barriers; waits are explicit.
+int g_gemm_persist = 1;          // seedmi_set_option("gemm_persist", 0|1)
 constexpr int B2 = 256;
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;          // 64 KiB per K-tile
 
 #define SEEDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// epilogue for the 32x32 accumulator layout: the lane owns row (mrow + 32*mt) and, per n-tile, 16 contiguous columns
+template <int EPI>
+SEEDMI_DEVINL void gemm_epilogue32(const GemmParams& p, f32x16 (&acc)[4][2], int mrow, int nb0) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int nb = nb0 + 32 * nt;
+        if (nb >= p.N) continue;
+        f32x4 a4[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a4[mt][q][r] = acc[mt][nt][4 * q + r];
+        // rows mrow + 32*mt: reuse the generic epilogue one row group at a time (MT = 1, row stride handled by the base)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 one[1][4] = {{a4[mt][0], a4[mt][1], a4[mt][2], a4[mt][3]}};
+            gemm_epilogue<EPI, 1>(p, one, mrow + 32 * mt, nb, 0);
+        }
+    }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
@@ -263,21 +290,41 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, g = lane >> 4;
 
-    int tm, tn;
-    tile_of_block(p, tm, tn);
-    const int m0 = tm * B2, n0 = tn * B2;
+    // ---- persistent tile walk: the launch holds one workgroup per CU; workgroup b (XCD b % 8) takes every
+    //      (workgroups-on-that-XCD)-th tile of its XCD's contiguous chunk of the grouped tile order, so the tiles
+    //      resident on an XCD at any time are neighbours sharing A / W panels in its L2.
+    const int nt = p.tiles_m * p.tiles_n;
+    int t_cur, t_end, t_stride;
+    {
+        const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+        const int cs = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
+        t_stride = ((int)gridDim.x + 7 - xcd) >> 3;
+        t_cur = cs + idx;
+        t_end = cs + q + (xcd < r ? 1 : 0);
+    }
+    if (t_cur >= t_end) return;                                        // uniform for the whole workgroup
 
-    // ---- LDS-DMA sources: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
+    int m0 = 0, n0 = 0;
     int offA[2][2], offW[2][2];
+    // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
+    auto set_tile = [&](int t) {
+        const int gsize = GROUP_M * p.tiles_n;
+        const int gid = t / gsize;
+        const int first_m = gid * GROUP_M;
+        const int gm = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = t - gid * gsize;
+        m0 = (first_m + in_g % gm) * B2;
+        n0 = (in_g / gm) * B2;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
-            const int cs = lane & 7;
-            offA[h][j] = min(m0 + row, p.M - 1) * p.lda + 8 * (cs ^ swzA(row));
-            offW[h][j] = min(n0 + row, p.N - 1) * p.ldw + 8 * (cs ^ swzW(row));
-        }
+            for (int j = 0; j < 2; ++j) {
+                const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
+                const int cs = lane & 7;
+                offA[h][j] = min(m0 + row, p.M - 1) * p.lda + 8 * (cs ^ swzA(row));
+                offW[h][j] = min(n0 + row, p.N - 1) * p.ldw + 8 * (cs ^ swzW(row));
+            }
+    };
     // ---- fragment read bases (byte offsets inside a K-tile buffer); tile index adds an immediate
     //   A: row = 16*mi + li inside half wm   (swizzle depends on li only)
     //   W: row = 64*wn + 16*(li>>2) + 4*ni + (li&3) inside the 256-row tile, half wn>>1 (swizzle independent of ni)
@@ -286,11 +333,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((g ^ swzW(rowW0)) << 4);
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const int nk = p.K / BK;
     auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
         char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
@@ -309,20 +351,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int j = 0; j < 2; ++j) glds16(p.W + (size_t)(offW[h][j] + k0), base + h * HALF_BYTES + j * 1024);
     };
 
-    // ---- prologue: K-tile 0 complete, W(1) already in flight
-    stageA(0);
-    stageW(0);
-    if (nk > 1) {
-        stageW(1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // prologue loads of a tile: K-tile 0 (A and W) and, already in flight behind it, W(1)
+    auto issue_prologue = [&]() {
+        stageA(0);
+        stageW(0);
+        if (nk > 1) stageW(1);
+    };
+    set_tile(t_cur);
+    issue_prologue();
+
+    bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh) k0/k1 x 4 tiles ; W(nh0), W(nh1): k0/k1 x 2 tiles
+    for (;;) {
+    const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // K-tile 0 complete (the up-to-4 youngest VM ops are W(1)'s LDS-DMA or the previous tile's epilogue stores)
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
     SEEDMI_SCHED_FENCE();
 
-    bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh) k0/k1 x 4 tiles ; W(nh0), W(nh1): k0/k1 x 2 tiles
     for (int kt = 0; kt < nk; ++kt) {
         const char* sb = smem + (kt & 1) * KT_BYTES;
         const char* pa0 = sb + rdA0;                    // k-step 0
@@ -410,8 +461,213 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
+    SEEDMI_SCHED_FENCE();
 
-    gemm_epilogue<EPI, 8>(p, acc, m0 + 128 * wm, n0 + 64 * wn + 16 * g, li);
+    // every LDS read of this tile is done: start the next tile's prologue loads now so that their latency (and the
+    // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
+    const int t_next = t_cur + t_stride;
+    const bool more = t_next < t_end;
+    if (more) {
+        set_tile(t_next);
+        issue_prologue();
+    }
+    gemm_epilogue<EPI, 8>(p, acc, em0 + 128 * wm, en0 + 64 * wn + 16 * g, li);
+    if (!more) break;
+    t_cur = t_next;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, g = lane >> 4;
+
+    // ---- persistent tile walk: the launch holds one workgroup per CU; workgroup b (XCD b % 8) takes every
+    //      (workgroups-on-that-XCD)-th tile of its XCD's contiguous chunk of the grouped tile order, so the tiles
+    //      resident on an XCD at any time are neighbours sharing A / W panels in its L2.
+    const int nt = p.tiles_m * p.tiles_n;
+    int t_cur, t_end, t_stride;
+    {
+        const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+        const int cs = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
+        t_stride = ((int)gridDim.x + 7 - xcd) >> 3;
+        t_cur = cs + idx;
+        t_end = cs + q + (xcd < r ? 1 : 0);
+    }
+    if (t_cur >= t_end) return;                                        // uniform for the whole workgroup
+
+    int m0 = 0, n0 = 0;
+    int offA[2][2], offW[2][2];
+    // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
+    auto set_tile = [&](int t) {
+        const int gsize = GROUP_M * p.tiles_n;
+        const int gid = t / gsize;
+        const int first_m = gid * GROUP_M;
+        const int gm = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = t - gid * gsize;
+        m0 = (first_m + in_g % gm) * B2;
+        n0 = (in_g / gm) * B2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
+                const int cs = lane & 7;
+                offA[h][j] = min(m0 + row, p.M - 1) * p.lda + 8 * (cs ^ swzA(row));
+                offW[h][j] = min(n0 + row, p.N - 1) * p.ldw + 8 * (cs ^ swzA(row));
+            }
+    };
+    // ---- fragment read bases for v_mfma_f32_32x32x16_bf16 (lane = row i in 0..31, k-half hl = lane >> 5; 16 k per step)
+    //   A (activations, MFMA B operand): row = 32*mt + i inside half wm; chunk = 2*ks + hl
+    //   W (weights, MFMA A operand): MFMA row rho = i feeds weight row 16*((rho>>2)&1) + 4*(rho>>3) + (rho&3) of the 32-row
+    //   n-tile, so that the accumulator registers of a lane (rho = 4*hl + (reg&3) + 8*(reg>>2)) are 16 CONTIGUOUS columns.
+    const int i32 = lane & 31, hl = lane >> 5;
+    const int rowW0 = 64 * wn + 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3);
+    const int rdA0 = wm * HALF_BYTES + i32 * 128 + ((hl ^ swzA(i32)) << 4);
+    const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((hl ^ swzA(rowW0)) << 4);
+
+    f32x16 acc[4][2];                                    // [m-tile of 32][n-tile of 32]
+    const int nk = p.K / BK;
+    auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
+        char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(p.A + (size_t)(offA[h][j] + k0), base + h * HALF_BYTES + j * 1024);
+    };
+    auto stageW = [&](int kt) {
+        char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(p.W + (size_t)(offW[h][j] + k0), base + h * HALF_BYTES + j * 1024);
+    };
+
+    // prologue loads of a tile: K-tile 0 (A and W) and, already in flight behind it, W(1)
+    auto issue_prologue = [&]() {
+        stageA(0);
+        stageW(0);
+        if (nk > 1) stageW(1);
+    };
+    set_tile(t_cur);
+    issue_prologue();
+
+    bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh): 2 m-tiles x 4 k-steps ; W(nh0), W(nh1): 4 k-steps each
+    for (;;) {
+    const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // K-tile 0 complete (the up-to-4 youngest VM ops are W(1)'s LDS-DMA or the previous tile's epilogue stores)
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
+    SEEDMI_SCHED_FENCE();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + (kt & 1) * KT_BYTES;
+        // k-step ks reads chunk (2*ks + hl) ^ swz  =  base ^ (ks << 5)
+#define PA(ks, mt) (*(const bf16x8*)(sb + ((rdA0 ^ ((ks) << 5)) + (mt) * 4096)))
+#define PW(ks, nt) (*(const bf16x8*)(sb + ((rdW0 ^ ((ks) << 5)) + (nt) * 4096)))
+
+        // ================= P1: (mh0, nh0) =================
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fw0[ks] = PW(ks, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fa[ks] = PA(ks, 0); fa[4 + ks] = PA(ks, 1); }
+        if (kt + 1 < nk) stageA(kt + 1);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw0[ks], fa[4 * mt + ks], acc[mt][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+
+        // ================= P2: (mh0, nh1) =================
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fw1[ks] = PW(ks, 1);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw1[ks], fa[4 * mt + ks], acc[mt][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+
+        // ================= P3: (mh1, nh1) =================
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fa[ks] = PA(ks, 2); fa[4 + ks] = PA(ks, 3); }
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[2 + mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw1[ks], fa[4 * mt + ks], acc[2 + mt][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+
+        // ================= P4: (mh1, nh0) =================
+        // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 2 < nk) stageW(kt + 2);               // W slots of this parity were last read in P2
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[2 + mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw0[ks], fa[4 * mt + ks], acc[2 + mt][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
+    SEEDMI_SCHED_FENCE();
+
+    // every LDS read of this tile is done: start the next tile's prologue loads now so that their latency (and the
+    // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
+    const int t_next = t_cur + t_stride;
+    const bool more = t_next < t_end;
+    if (more) {
+        set_tile(t_next);
+        issue_prologue();
+    }
+    gemm_epilogue32<EPI>(p, acc, em0 + 128 * wm + i32, en0 + 64 * wn + 16 * hl);
+    if (!more) break;
+    t_cur = t_next;
+    }
+#undef PA
+#undef PW
 }
 
 template <int EPI>
@@ -423,8 +679,37 @@ int launch_gemm256(GemmParams p, hipStream_t stream) {
     }
     p.tiles_m = (p.M + B2 - 1) / B2;
     p.tiles_n = (p.N + B2 - 1) / B2;
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * KT_BYTES, stream, p);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int nt = p.tiles_m * p.tiles_n;
+    const int grid = (g_gemm_persist && nt > n_cu) ? n_cu : nt;
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), 2 * KT_BYTES, stream, p);
     return seedmi_check_launch("gemm256");
+}
+
+template <int EPI>
+int launch_gemm256x(GemmParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256x_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES);
+        attr_set = true;
+    }
+    p.tiles_m = (p.M + B2 - 1) / B2;
+    p.tiles_n = (p.N + B2 - 1) / B2;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int nt = p.tiles_m * p.tiles_n;
+    const int grid = (g_gemm_persist && nt > n_cu) ? n_cu : nt;
+    hipLaunchKernelGGL(gemm256x_kernel<EPI>, dim3(grid), dim3(512), 2 * KT_BYTES, stream, p);
+    return seedmi_check_launch("gemm256x");
 }
 
 template <int EPI>
@@ -444,6 +729,7 @@ int g_gemm_variant = 0;      // 0 = auto, 128 / 256 = force a kernel (seedmi_set
 template <int EPI>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     const bool big = p.M >= 1024 && p.N >= 256;
+    if (g_gemm_variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
     const bool use256 = g_gemm_variant == 256 || (g_gemm_variant == 0 && big && SEEDMI_GEMM256_DEFAULT);
     return use256 ? launch_gemm256<EPI>(p, s) : launch_gemm128<EPI>(p, s);
 }
@@ -451,12 +737,17 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int seedmi_set_option(const char* key, int value) {
-    if (key && !strcmp(key, "gemm") && (value == 0 || value == 128 || value == 256)) {
+    if (key && !strcmp(key, "gemm") && (value == 0 || value == 128 || value == 256 || value == 232)) {
         g_gemm_variant = value;
+        return SEEDMI_OK;
+    }
+    if (key && !strcmp(key, "gemm_persist") && (value == 0 || value == 1)) {
+        g_gemm_persist = value;
         return SEEDMI_OK;
     }
     if (key && !strcmp(key, "tokenize_streams") && seedmi_tokenizer_set_streams(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_llama_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
+    if (key && seedmi_attn_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);
     return SEEDMI_E_SHAPE;
 }

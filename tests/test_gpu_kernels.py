@@ -69,7 +69,7 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[128, 256], ids=["gemm128", "gemm256"])
+@pytest.fixture(params=[128, 256, 232], ids=["gemm128", "gemm256", "gemm256x32"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (128x128 two-barrier and 256x256 staggered deep pipeline)."""
     L.check(lib.seedmi_set_option(b"gemm", request.param), "set_option")
@@ -242,7 +242,9 @@ def ref_attention(q, k, v, heads, scale, causal, round_s=True):
     (4, 12, 64, 32, 257, False),      # Q-Former cross-attention
     (2, 2, 64, 17, 17, False),
 ])
-def test_attention_fullrow(lib, B, H, hd, nq, nk, causal):
+@pytest.mark.parametrize("trv", [1, 0], ids=["tr_read", "vt_image"])
+def test_attention_fullrow(lib, B, H, hd, nq, nk, causal, trv):
+    L.check(lib.seedmi_set_option(b"attn_trv", trv), "set_option")
     gen = torch.Generator().manual_seed(B * 100 + nk)
     C = H * hd
     # packed [q|k|v] buffer like the ViT QKV GEMM output
@@ -264,7 +266,8 @@ def test_attention_fullrow(lib, B, H, hd, nq, nk, causal):
     kf = K[:, :C].float().reshape(B, nk, C)
     vf = V[:, :C].float().reshape(B, nk, C)
     want = ref_attention(qf, kf, vf, H, scale, causal)
-    assert_close_bf16(out.view(B, nq, C), want, f"attention hd{hd} {nq}x{nk} causal={causal}", atol_ulps=2.5, frac=0.995)
+    lib.seedmi_set_option(b"attn_trv", 1)
+    assert_close_bf16(out.view(B, nq, C), want, f"attention hd{hd} {nq}x{nk} causal={causal} trv={trv}", atol_ulps=2.5, frac=0.995)
 
 
 def test_vq_argmin_bit_exact(lib, golden_dir):

@@ -24,10 +24,11 @@ for name, M, N, K, epi in SHAPES:
     bias = (torch.randn(N, device="cuda", generator=g) * 0.1).bfloat16()
     R = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi == L.EPI_BIAS_RESIDUAL else None
     outs = {}
-    times = {128: [], 256: []}
+    times = {128: [], 256: [], 257: [], 232: []}
     for rnd in range(6):
-        for v in (128, 256):
-            L.check(lib.seedmi_set_option(b"gemm", v), "set_option")
+        for v in (128, 256, 257, 232):                      # 257 = the 256 kernel launched persistent (one workgroup per CU)
+            L.check(lib.seedmi_set_option(b"gemm", 256 if v == 257 else v), "set_option")
+            L.check(lib.seedmi_set_option(b"gemm_persist", 1 if v in (257, 232) else 0), "set_option")
             C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -38,12 +39,15 @@ for name, M, N, K, epi in SHAPES:
             if rnd > 0:
                 times[v].append(e0.elapsed_time(e1))
             outs[v] = C
-    same = torch.equal(outs[128], outs[256])
+    same = torch.equal(outs[128], outs[256]) and torch.equal(outs[128], outs[257])
+    same32 = torch.equal(outs[128], outs[232])
+    relx = ((outs[232].float() - outs[128].float()).norm() / outs[128].float().norm()).item()
     fl = 2.0 * M * N * K
     r = {v: round(fl / (sorted(t)[len(t) // 2] * 1e-3) / 1e12, 1) for v, t in times.items()}
-    res[name] = {"M": M, "N": N, "K": K, "TF_128": r[128], "TF_256": r[256], "bit_identical": same,
+    res[name] = {"M": M, "N": N, "K": K, "TF_128": r[128], "TF_256": r[256], "TF_256_persistent": r[257], "TF_256x32": r[232], "bit_identical": same, "x32_identical": same32, "x32_rel": relx,
                  "ms_128": round(sorted(times[128])[2], 4), "ms_256": round(sorted(times[256])[2], 4)}
     print(name, res[name], flush=True)
 lib.seedmi_set_option(b"gemm", 0)
+lib.seedmi_set_option(b"gemm_persist", 1)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/gemm_bench.json", "w"), indent=1)
