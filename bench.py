@@ -116,7 +116,7 @@ def llama_decode_leg(B, n_new):
     prompt = torch.randint(3, 32000, (B, T0), device="cuda", generator=g)
     prompt[:, 0] = 1
     prompt[:, 10:42] = 32000 + torch.randint(0, 8192, (B, 32), device="cuda", generator=g)   # <img_XXXXX> x 32
-    eng.greedy_decode(prompt, 4)                                   # warm-up
+    eng.greedy_decode_graph(prompt, 4)                             # warm-up (kernels, allocator, graph machinery)
     torch.cuda.synchronize()
     eng.reset()
     t0 = time.time()
@@ -124,12 +124,13 @@ def llama_decode_leg(B, n_new):
     torch.cuda.synchronize()
     t_prefill = time.time() - t0
     tok = logits[:, 0].float().argmax(-1, keepdim=True)
+    replay, out = eng.capture_decode_graph(tok, n_new)             # one captured step, replayed n_new-1 times
+    torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(n_new - 1):
-        logits = eng.forward(tok, last_only=True)
-        tok = logits[:, 0].float().argmax(-1, keepdim=True)
+    replay(n_new - 1)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    assert int(out.min()) >= 0 and int(out.max()) < cfg.vocab
     steps = n_new - 1
     tok_s = B * steps / dt
     ctx_mid = T0 + n_new // 2

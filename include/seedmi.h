@@ -102,13 +102,15 @@ int seedmi_embed_rows(const void* ids_i64, const void* table, int ldt, void* out
  * caches [B][H][tmax][hd] written at positions past_len..past_len+T-1.  cos/sin: [max_pos, hd] bf16 tables. */
 int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t, const void* sin_t,
                           void* q_out, int ldq, void* k_cache, void* v_cache, int B, int T, int H, int hd, int tmax,
-                          int past_len, void* stream);
+                          int past_len, const void* past_len_dev, void* stream);
+/* *counter += delta on the stream (the decode graph advances its device-resident cache length with it). */
+int seedmi_add_i32(void* counter_dev, int delta, void* stream);
 /* xformers.ops.memory_efficient_attention semantics (llama_xformer.py:244-256), head_dim 128:
  * q [B*T, H*hd]; caches [B][H][tmax][hd] holding kv_len = past_len + T keys; causal (top-left aligned on the
  * last T positions) when T > 1. */
 int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k_cache, const void* v_cache, void* out, int ldo,
                                 int B, int T, int H, int hd, int tmax, int past_len, float scale, int out_packed,
-                                void* stream);
+                                const void* past_len_dev, void* stream);
 /* Skinny GEMM for decode (M <= 64): same contract as seedmi_gemm_bf16 restricted to NONE/BIAS_RESIDUAL/SWIGLU. */
 int seedmi_gemm_skinny_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* residual,
                             int ldr, int epilogue, void* C, int ldc, void* stream);
@@ -201,6 +203,13 @@ size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, int batch, 
 int seedmi_llama_forward(const seedmi_llama_weights_t* w, const void* ids_i64, const void* pos_i64, int batch, int T,
                          int past_len, int last_only, void* logits, int ldl, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* Same with the cache length read from device memory (int32*) by the kernels that need it (T must be 1; positions are
+ * taken as *past_len_dev when pos_i64 is NULL): no launch argument changes from step to step, so one captured
+ * hipGraph of this call replays the whole decode loop (the reference pays a host round trip per layer per step,
+ * llama_xformer.py:255). past_len is still needed on the host for capacity checks (pass the current upper bound). */
+int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const void* ids_i64, const void* pos_i64, int batch, int T,
+                            int past_len, const void* past_len_dev, int last_only, void* logits, int ldl, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -227,6 +227,7 @@ int launch_attn(const AttnParams& p, int batch, hipStream_t stream) {
 
 int seedmi_attn_set_option(const char* key, int value) {
     if (!strcmp(key, "attn_trv") && (value == 0 || value == 1)) { g_attn_trv = value; return SEEDMI_OK; }
+    if (!strcmp(key, "attn_vit") && (value == 0 || value == 1)) return seedmi_attn_vit_set(value);
     return SEEDMI_E_SHAPE;
 }
 
@@ -249,6 +250,11 @@ extern "C" int seedmi_attention_bf16(const void* Q, int ldq, const void* K, int 
     p.nq = nq; p.nk = nk; p.heads = heads; p.scale = scale;
     hipStream_t s = (hipStream_t)stream;
     const bool rs = round_scores != 0;
+    {   // the persistent LDS-DMA pipeline handles the ViT shape (head_dim 88, 64..272 tokens, no mask)
+        const int rc = seedmi_attention_vit_try(Q, ldq, K, ldk, V, ldv, O, ldo, batch, heads, head_dim, nq, nk, scale, causal,
+                                                round_scores, stream);
+        if (rc <= 0) return rc;
+    }
     if (causal && nq != nk) {
         seedmi_set_error("seedmi_attention_bf16: causal needs nq == nk (got %d, %d)", nq, nk);
         return SEEDMI_E_SHAPE;

@@ -1,0 +1,249 @@
+// ViT attention (eva_vit.py:139-156) as a persistent, fully staged pipeline on gfx950: head_dim 88, <= 288 keys.
+//
+// One workgroup (12 waves) per CU walks (image, head) items.  Per item:
+//     wait K | QK^T + softmax (P kept packed in registers) | wait V | PV | store
+// with every HBM->LDS transfer issued by LDS-DMA one stage ahead, so that nothing is ever waited for cold:
+//     K(i+1) is requested right before PV(i)   (the K image is free once every wave has finished QK^T(i)),
+//     V(i+1) right after PV(i)                 (lands during QK^T(i+1)),
+//     Q(i+1) fragments are prefetched into registers before V(i+1) is requested so that their wait does not
+//     drag V(i+1) along (vmcnt retires in order).
+// K and V live in LDS row-major with UNPADDED 176-byte rows (11 x 16 B: an odd number of 16-byte slots keeps
+// ds_read_b128 / ds_read_b64_tr_b16 at <= 2-way conflicts) because LDS-DMA writes lane-linear images; the head
+// dim is padded to 96 on the register side instead: the Q fragment's last 16-byte chunk is zero, so whatever the
+// K read picks up from the next row is multiplied by 0, and the spilled V columns 88..95 are never stored.
+// Same arithmetic and rounding points as attn_fullrow.hip (q*scale -> half, S -> half, P normalised -> half).
+#include <string.h>
+#include "common.h"
+#include "seedmi_internal.h"
+
+namespace {
+
+constexpr int VHD = 88, VCH = 11, VNKP = 288, VNT = 18, VKK = 9, VHT = 6;
+constexpr int VROWS = VNKP + 1;                         // one spill row for the 96-wide reads of the last key
+constexpr int VWAVES = 12;
+constexpr int VMAT_BYTES = VROWS * VHD * 2;             // 50,864 B per matrix image
+
+struct VitAttnParams {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
+    int ldq, ldk, ldv, ldo;
+    int n, heads, items;
+    float scale;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+SEEDMI_DEVINL void glds16v(const bf16_t* gptr, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool ROUND_S>
+__global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ksm = (bf16_t*)smem;
+    bf16_t* Vsm = (bf16_t*)(smem + VMAT_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = p.n;
+    const int total_chunks = n * VCH;
+    const int npieces = (total_chunks + 63) >> 6;                     // 1 KiB LDS-DMA pieces per matrix
+    const int my_pieces = (npieces - wave + VWAVES - 1) / VWAVES;     // pieces wave, wave+12, ... (wave-uniform)
+    const int nqt = (n + 15) >> 4;
+    const int my_tiles = (nqt - wave + VWAVES - 1) / VWAVES;          // q-tiles wave, wave+12 (<= 2)
+
+    // V image: rows >= n must hold finite values (they meet P == 0); zero the whole image once
+    for (int i = tid; i < VMAT_BYTES / 16; i += 64 * VWAVES) *(uint4*)(smem + VMAT_BYTES + 16 * i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    auto stage = [&](const bf16_t* base, int ld, bf16_t* dst, int item) {
+        const int b = item / p.heads, h = item - b * p.heads;
+        const bf16_t* src = base + (size_t)b * n * ld + h * VHD;
+        for (int j = 0; j < my_pieces; ++j) {
+            const int piece = wave + VWAVES * j;
+            const int q = min(64 * piece + lane, total_chunks - 1);  // clamped lanes copy a valid (finite) chunk
+            const int row = q / VCH, c = q - row * VCH;
+            glds16v(src + (size_t)row * ld + 8 * c, (char*)dst + piece * 1024);
+        }
+    };
+    auto load_q = [&](bf16x8 (&qf)[2][3], int item) {
+        const int b = item / p.heads, h = item - b * p.heads;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qrow = 16 * (wave + VWAVES * t) + li;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int c0 = 32 * ks + 8 * g;
+                if (t < my_tiles && qrow < n && c0 < VHD) v = *(const uint4*)(p.Q + ((size_t)b * n + qrow) * p.ldq + h * VHD + c0);
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = pack2bf(lo_bf(w[i]) * p.scale, hi_bf(w[i]) * p.scale);
+                qf[t][ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+        }
+    };
+    auto wait_vm = [&](int leave) {                                   // leave is wave-uniform and one of 0,3,4
+        if (leave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (leave == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (leave == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (leave == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+
+    int item = blockIdx.x;
+    if (item >= p.items) return;
+    bf16x8 qf[2][3];
+    stage(p.K, p.ldk, Ksm, item);
+    load_q(qf, item);
+    stage(p.V, p.ldv, Vsm, item);
+
+    for (;;) {
+        const int b = item / p.heads, h = item - b * p.heads;
+        // ---- K(item) landed everywhere (only this wave's V pieces may still be in flight)
+        wait_vm(my_pieces);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- S^T = K Q^T and softmax per q-tile; P packed to bf16 MFMA operands and kept in registers
+        bf16x8 pf[2][VKK];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < my_tiles) {
+                const int qrow = 16 * (wave + VWAVES * t) + li;
+                f32x4 s[VNT];
+#pragma unroll
+                for (int kt = 0; kt < VNT; ++kt) {
+                    s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        const bf16x8 kf = *(const bf16x8*)(Ksm + (16 * kt + li) * VHD + 32 * ks + 8 * g);
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
+                    }
+                    if ((kt % 3) == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < VNT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = ROUND_S ? rbf(s[kt][r]) : s[kt][r];
+                        if (16 * kt + 15 >= n) v = (16 * kt + 4 * g + r >= n) ? -INFINITY : v;
+                        s[kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < VNT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(s[kt][r] - mx);
+                        s[kt][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int kk = 0; kk < VKK; ++kk) {
+                    uint4 pw;
+                    pw.x = pack2bf(s[2 * kk][0] * inv, s[2 * kk][1] * inv);
+                    pw.y = pack2bf(s[2 * kk][2] * inv, s[2 * kk][3] * inv);
+                    pw.z = pack2bf(s[2 * kk + 1][0] * inv, s[2 * kk + 1][1] * inv);
+                    pw.w = pack2bf(s[2 * kk + 1][2] * inv, s[2 * kk + 1][3] * inv);
+                    pf[t][kk] = __builtin_bit_cast(bf16x8, pw);
+                }
+            }
+        }
+
+        // ---- V(item) landed; every wave is done with K(item)
+        wait_vm(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int next = item + gridDim.x;
+        const bool more = next < p.items;
+        if (more) stage(p.K, p.ldk, Ksm, next);
+
+        // ---- O^T = V^T P^T (hardware transpose read of the row-major V image), store
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < my_tiles) {
+                f32x4 o[VHT];
+#pragma unroll
+                for (int nn = 0; nn < VHT; ++nn) o[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < VKK; ++kk) {
+#pragma unroll
+                    for (int nn = 0; nn < VHT; ++nn) {
+                        const bf16_t* vp = Vsm + (32 * kk + 4 * g + (li >> 2)) * VHD + 16 * nn + 4 * (li & 3);
+                        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
+                        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 16 * VHD));
+                        const uint2 lo = __builtin_bit_cast(uint2, a), hi = __builtin_bit_cast(uint2, c);
+                        const uint4 vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf[t][kk], o[nn], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int qrow = 16 * (wave + VWAVES * t) + li;
+                if (qrow < n) {
+                    bf16_t* op = p.O + ((size_t)b * n + qrow) * p.ldo + h * VHD;
+#pragma unroll
+                    for (int nn = 0; nn < VHT; ++nn) {
+                        const int c0 = 16 * nn + 4 * g;
+                        if (c0 + 4 <= VHD) {
+                            uint2 w;
+                            w.x = pack2bf(o[nn][0], o[nn][1]);
+                            w.y = pack2bf(o[nn][2], o[nn][3]);
+                            *(uint2*)(op + c0) = w;
+                        }
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        load_q(qf, next);                                          // before V(next): its wait must not include V(next)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                              // every wave is done with V(item)
+        stage(p.V, p.ldv, Vsm, next);
+        item = next;
+    }
+}
+
+int g_attn_vit = 1;
+
+}  // namespace
+
+int seedmi_attn_vit_enabled() { return g_attn_vit; }
+int seedmi_attn_vit_set(int v) { g_attn_vit = v; return SEEDMI_OK; }
+
+// returns SEEDMI_OK after launching, or 1 if the shape is not handled by this kernel (caller falls back to attn_fullrow)
+int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                             int batch, int heads, int head_dim, int nq, int nk, float scale, int causal, int round_scores,
+                             void* stream) {
+    if (!g_attn_vit || head_dim != VHD || causal || nq != nk || nk > VNKP - 16 || nk < 64) return 1;
+    VitAttnParams p;
+    p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.n = nq; p.heads = heads; p.items = batch * heads; p.scale = scale;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int grid = p.items < n_cu ? p.items : n_cu;
+    constexpr int lds = 2 * VMAT_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_vit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    if (round_scores)
+        hipLaunchKernelGGL(attn_vit_kernel<true>, dim3(grid), dim3(64 * VWAVES), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(attn_vit_kernel<false>, dim3(grid), dim3(64 * VWAVES), lds, (hipStream_t)stream, p);
+    return seedmi_check_launch("attn_vit");
+}

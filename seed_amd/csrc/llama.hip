@@ -201,11 +201,13 @@ constexpr int DEC_HD = 128;
 
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int ldq,
                                                           const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
-                                                          bf16_t* __restrict__ out, int ldo, int H, int tmax, int kv_len,
-                                                          float scale, int out_packed) {
+                                                          bf16_t* __restrict__ out, int ldo, int H, int tmax, int kv_len_arg,
+                                                          float scale, int out_packed, int lds_len,
+                                                          const int* __restrict__ past_dev) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int kv_len = past_dev ? *past_dev + 1 : kv_len_arg;     // device-resident length: graph-replayable decode step
     float* sc = dsm;                                // [kv_len] scores -> probabilities
-    float* part = dsm + ((kv_len + 3) & ~3);        // [16][128] partial outputs
+    float* part = dsm + lds_len;                    // [16][128] partial outputs
     __shared__ float wred[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -520,7 +522,11 @@ extern "C" int seedmi_pack_skinny_weights(const void* W, int ldw, int N, int K, 
 
 extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k_cache, const void* v_cache, void* out,
                                            int ldo, int B, int T, int H, int hd, int tmax, int past_len, float scale,
-                                           int out_packed, void* stream) {
+                                           int out_packed, const void* past_len_dev, void* stream) {
+    if (past_len_dev && T != 1) {
+        seedmi_set_error("seedmi_llama_attention_bf16: device-resident past_len is a decode (T == 1) feature");
+        return SEEDMI_E_SHAPE;
+    }
     if (out_packed && T != 1) {
         seedmi_set_error("seedmi_llama_attention_bf16: packed output is a decode (T == 1) feature");
         return SEEDMI_E_SHAPE;
@@ -536,7 +542,9 @@ extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k
     hipStream_t s = (hipStream_t)stream;
     if (T == 1) {
         const int kv_len = past_len + 1;
-        const size_t lds = (size_t)(((kv_len + 3) & ~3) + 16 * DEC_HD) * sizeof(float);
+        // with a device-resident length the launch must cover any length up to the cache capacity
+        const int lds_len = ((past_len_dev ? tmax : kv_len) + 3) & ~3;
+        const size_t lds = (size_t)(lds_len + 16 * DEC_HD) * sizeof(float);
         if (lds > 150 * 1024) {
             seedmi_set_error("seedmi_llama_attention_bf16: kv_len %d too long for the decode kernel", kv_len);
             return SEEDMI_E_SHAPE;
@@ -547,7 +555,8 @@ extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k
             attr_set = true;
         }
         hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(256), lds, s, (const bf16_t*)q, ldq, (const bf16_t*)k_cache,
-                           (const bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, kv_len, scale, out_packed);
+                           (const bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, kv_len, scale, out_packed, lds_len,
+                           (const int*)past_len_dev);
         return seedmi_check_launch("attn_decode");
     }
     const int qblocks = (T + 63) / 64;
@@ -564,8 +573,19 @@ extern "C" size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, 
 extern "C" int seedmi_llama_forward(const seedmi_llama_weights_t* w, const void* ids_i64, const void* pos_i64, int batch,
                                     int T, int past_len, int last_only, void* logits, int ldl, void* workspace,
                                     size_t workspace_bytes, void* stream) {
-    if (!w || !ids_i64 || !pos_i64 || !logits || batch <= 0 || T <= 0) {
+    return seedmi_llama_forward_ex(w, ids_i64, pos_i64, batch, T, past_len, nullptr, last_only, logits, ldl, workspace,
+                                   workspace_bytes, stream);
+}
+
+extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const void* ids_i64, const void* pos_i64, int batch,
+                                       int T, int past_len, const void* past_len_dev, int last_only, void* logits, int ldl,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!w || !ids_i64 || (!pos_i64 && !past_len_dev) || !logits || batch <= 0 || T <= 0) {
         seedmi_set_error("seedmi_llama_forward: null argument or bad batch/T");
+        return SEEDMI_E_SHAPE;
+    }
+    if (past_len_dev && T != 1) {
+        seedmi_set_error("seedmi_llama_forward_ex: a device-resident past_len is only valid for single-token decode steps");
         return SEEDMI_E_SHAPE;
     }
     if (batch > w->batch_cap || past_len + T > w->tmax || past_len + T > w->max_pos) {
@@ -591,10 +611,10 @@ extern "C" int seedmi_llama_forward(const seedmi_llama_weights_t* w, const void*
         if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, M, h, stream));
         else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, h, M, h, stream));
         CK(linear(M, 3 * h, h, t.xn, h, L.qkv_w, L.qkv_wp, nullptr, 0, EPI_NONE, t.qkv, 3 * h, stream, pk, 0));
-        CK(seedmi_rope_kv_append(t.qkv, 3 * h, pos_i64, w->cos_t, w->sin_t, t.q, h, L.k_cache, L.v_cache, batch, T, H, hd,
-                                 w->tmax, past_len, stream));
+        CK(seedmi_rope_kv_append(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, t.q, h, L.k_cache,
+                                 L.v_cache, batch, T, H, hd, w->tmax, past_len, past_len_dev, stream));
         CK(seedmi_llama_attention_bf16(t.q, h, L.k_cache, L.v_cache, t.att, h, batch, T, H, hd, w->tmax, past_len, scale,
-                                       pk, stream));
+                                       pk, past_len_dev, stream));
         CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
         if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, M, h, stream));
         else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, h, M, h, stream));

@@ -186,7 +186,11 @@ __global__ void embed_rows_kernel(const long long* __restrict__ ids, const bf16_
 __global__ void rope_kv_append_kernel(const bf16_t* __restrict__ qkv, int ldqkv, const long long* __restrict__ pos_ids,
                                       const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t,
                                       bf16_t* __restrict__ q_out, int ldq, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
-                                      int B, int T, int H, int hd, int tmax, int past_len) {
+                                      int B, int T, int H, int hd, int tmax, int past_len_arg,
+                                      const int* __restrict__ past_dev) {
+    // past_dev: the cache length lives in device memory so that a captured hipGraph of the decode step can be replayed
+    // for every position (a kernel argument would be frozen at capture time)
+    const int past_len = past_dev ? *past_dev : past_len_arg;
     const int half = hd >> 1;
     const int pairs = half >> 2;                       // 4 element pairs (x[i], x[i+half]) per thread
     const long long total = (long long)B * T * H * pairs;
@@ -198,7 +202,7 @@ __global__ void rope_kv_append_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
         const int t = (int)(r % T);
         const int b = (int)(r / T);
         const long long row = (long long)b * T + t;
-        const long long pos = pos_ids[row];
+        const long long pos = pos_ids ? pos_ids[row] : (long long)(past_len + t);
         const int i0 = pc * 4;
         const bf16_t* cs = cos_t + pos * hd;
         const bf16_t* sn = sin_t + pos * hd;
@@ -227,6 +231,8 @@ __global__ void rope_kv_append_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
         }
     }
 }
+
+__global__ void add_i32_kernel(int* p, int delta) { *p += delta; }
 
 int grid_for(long long total, int block) {
     long long g = (total + block - 1) / block;
@@ -293,6 +299,11 @@ extern "C" int seedmi_fill_rows(void* dst, int ld, int group_rows, int r0, int n
     return seedmi_check_launch("fill_rows");
 }
 
+extern "C" int seedmi_add_i32(void* counter_dev, int delta, void* stream) {
+    hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)counter_dev, delta);
+    return seedmi_check_launch("add_i32");
+}
+
 extern "C" int seedmi_embed_rows(const void* ids_i64, const void* table, int ldt, void* out, int ldo, int n, int cols,
                                  int vocab, void* stream) {
     if (n <= 0 || cols % 8 || ldt % 8 || ldo % 8) {
@@ -307,7 +318,7 @@ extern "C" int seedmi_embed_rows(const void* ids_i64, const void* table, int ldt
 
 extern "C" int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t,
                                      const void* sin_t, void* q_out, int ldq, void* k_cache, void* v_cache, int B, int T,
-                                     int H, int hd, int tmax, int past_len, void* stream) {
+                                     int H, int hd, int tmax, int past_len, const void* past_len_dev, void* stream) {
     if (B <= 0 || T <= 0 || H <= 0 || (hd % 8) || past_len + T > tmax) {
         seedmi_set_error("seedmi_rope_kv_append: bad shape B=%d T=%d H=%d hd=%d past=%d tmax=%d", B, T, H, hd, past_len, tmax);
         return SEEDMI_E_SHAPE;
@@ -315,6 +326,7 @@ extern "C" int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos
     const long long total = (long long)B * T * H * (hd / 8);
     hipLaunchKernelGGL(rope_kv_append_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qkv, ldqkv, (const long long*)pos_ids_i64, (const bf16_t*)cos_t, (const bf16_t*)sin_t,
-                       (bf16_t*)q_out, ldq, (bf16_t*)k_cache, (bf16_t*)v_cache, B, T, H, hd, tmax, past_len);
+                       (bf16_t*)q_out, ldq, (bf16_t*)k_cache, (bf16_t*)v_cache, B, T, H, hd, tmax, past_len,
+                       (const int*)past_len_dev);
     return seedmi_check_launch("rope_kv_append");
 }

@@ -18,3 +18,8 @@ int seedmi_tokenizer_set_streams(int n);
 // seedmi_set_option("skinny_nt" | "skinny_waves", v): decode GEMM experiments (llama.hip)
 int seedmi_llama_set_option(const char* key, int value);
 int seedmi_attn_set_option(const char* key, int value);
+// attn_vit.hip: persistent ViT attention; returns 1 when the shape is not its own
+int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                             int batch, int heads, int head_dim, int nq, int nk, float scale, int causal, int round_scores,
+                             void* stream);
+int seedmi_attn_vit_set(int v);

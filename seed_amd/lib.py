@@ -67,8 +67,9 @@ SIGNATURES = {
     "seedmi_vq_code_sqnorm": (_i, [_vp, _vp, _i, _i, _vp]),
     "seedmi_vq_argmin_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "seedmi_embed_rows": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
-    "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "seedmi_llama_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
+    "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "seedmi_add_i32": (_i, [_vp, _i, _vp]),
+    "seedmi_llama_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp, _vp]),
     "seedmi_gemm_skinny_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "seedmi_pack_skinny_weights_bytes": (C.c_size_t, [_i, _i]),
     "seedmi_pack_skinny_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -79,6 +80,7 @@ SIGNATURES = {
                              C.c_size_t, _vp]),
     "seedmi_llama_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaWeights), _i, _i]),
     "seedmi_llama_forward": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.c_size_t, _vp]),
+    "seedmi_llama_forward_ex": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, C.c_size_t, _vp]),
 }
 
 

@@ -149,6 +149,74 @@ class LlamaEngine:
         self.past_len = past_len + T
         return logits.view(B, Tout, self.vocab_pad)[:, :, :cfg.vocab]
 
+    # ------------------------------------------------------------------ hipGraph decode loop
+    def _decode_step_graphed(self, tok: torch.Tensor, logits: torch.Tensor, counter: torch.Tensor, ws: torch.Tensor):
+        """One single-token step whose launch arguments never change: the cache length is read from ``counter``
+        (device int32) by the RoPE/KV-append and attention kernels, then advanced on the stream."""
+        B = tok.shape[0]
+        rc = self.lib.seedmi_llama_forward_ex(C.byref(self.w), L.ptr(tok), None, B, 1, self.tmax - 1, L.ptr(counter), 1,
+                                              L.ptr(logits), self.vocab_pad, L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, "seedmi_llama_forward_ex")
+        L.check(self.lib.seedmi_add_i32(L.ptr(counter), 1, L.stream_ptr()), "seedmi_add_i32")
+
+    def capture_decode_graph(self, first_tok: torch.Tensor, n_new: int):
+        """Capture one greedy single-token step (forward + argmax + bookkeeping) as a hipGraph, starting from the
+        engine's current cache length.  Returns (replay, out) where ``replay(k)`` runs k further steps (stream ordered)
+        and ``out`` [B, n_new] receives the tokens (column 0 = first_tok)."""
+        B = first_tok.shape[0]
+        if self.past_len + n_new - 1 > self.tmax:
+            raise L.SeedmiError(f"decode would exceed the KV cache ({self.past_len}+{n_new - 1} > {self.tmax})")
+        tok = first_tok.to(torch.int64).reshape(B, 1).contiguous().clone()
+        out = torch.zeros(B, n_new, dtype=torch.int64, device=self.device)
+        out[:, 0:1] = tok
+        counter = torch.tensor([self.past_len], dtype=torch.int32, device=self.device)
+        logits = torch.empty(B, self.vocab_pad, dtype=torch.bfloat16, device=self.device)
+        ws = self._workspace(B, 1)
+        step_idx = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+        def body():
+            self._decode_step_graphed(tok, logits, counter, ws)
+            nxt = logits[:, :self.cfg.vocab].float().argmax(-1, keepdim=True)
+            tok.copy_(nxt)
+            step_idx.add_(1)
+            out.scatter_(1, step_idx.expand(B, 1), nxt)
+
+        # warm-up on a side stream (required before capture), then rewind its side effects
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        tok0, cnt0, out0 = tok.clone(), counter.clone(), out.clone()
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        tok.copy_(tok0)
+        counter.copy_(cnt0)
+        out.copy_(out0)
+        step_idx.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        keep = (tok, counter, logits, ws, step_idx)          # buffers referenced by the graph
+
+        def replay(k: int):
+            for _ in range(k):
+                graph.replay()
+            self.past_len += k
+            return keep and out
+        return replay, out
+
+    def greedy_decode_graph(self, prompt_ids: torch.Tensor, n_new: int):
+        """Greedy decode with the per-token step captured once as a hipGraph and replayed: ~290 kernel launches per
+        step collapse into one graph launch (the decode step is launch/HBM bound; the reference additionally syncs
+        the host once per layer per step, llama_xformer.py:255).  Returns tokens [B, n_new]."""
+        self.reset()
+        logits0 = self.forward(prompt_ids, last_only=True)
+        tok = logits0[:, 0].float().argmax(-1, keepdim=True)
+        if n_new == 1:
+            return tok
+        replay, out = self.capture_decode_graph(tok, n_new)
+        replay(n_new - 1)
+        return out
+
     def greedy_decode(self, prompt_ids: torch.Tensor, n_new: int):
         """Greedy loop (argmax on device, no host sync inside the loop). Returns (tokens [B,n_new], per-step logits)."""
         self.reset()

@@ -237,14 +237,17 @@ def ref_attention(q, k, v, heads, scale, causal, round_s=True):
 
 @pytest.mark.parametrize("B,H,hd,nq,nk,causal", [
     (3, 16, 88, 257, 257, False),     # ViT
+    (40, 16, 88, 257, 257, False),    # ViT, more items than CUs (persistent kernel walks > 1 item per workgroup)
+    (2, 3, 88, 100, 100, False),
     (2, 4, 88, 17, 17, False),        # small ViT (NKP=32 path)
     (5, 12, 64, 32, 32, True),        # Q-Former causal self-attention
     (4, 12, 64, 32, 257, False),      # Q-Former cross-attention
     (2, 2, 64, 17, 17, False),
 ])
-@pytest.mark.parametrize("trv", [1, 0], ids=["tr_read", "vt_image"])
+@pytest.mark.parametrize("trv", [2, 1, 0], ids=["vit_pipeline", "tr_read", "vt_image"])
 def test_attention_fullrow(lib, B, H, hd, nq, nk, causal, trv):
-    L.check(lib.seedmi_set_option(b"attn_trv", trv), "set_option")
+    L.check(lib.seedmi_set_option(b"attn_vit", 1 if trv == 2 else 0), "set_option")
+    L.check(lib.seedmi_set_option(b"attn_trv", min(trv, 1)), "set_option")
     gen = torch.Generator().manual_seed(B * 100 + nk)
     C = H * hd
     # packed [q|k|v] buffer like the ViT QKV GEMM output
@@ -267,6 +270,7 @@ def test_attention_fullrow(lib, B, H, hd, nq, nk, causal, trv):
     vf = V[:, :C].float().reshape(B, nk, C)
     want = ref_attention(qf, kf, vf, H, scale, causal)
     lib.seedmi_set_option(b"attn_trv", 1)
+    lib.seedmi_set_option(b"attn_vit", 1)
     assert_close_bf16(out.view(B, nq, C), want, f"attention hd{hd} {nq}x{nk} causal={causal} trv={trv}", atol_ulps=2.5, frac=0.995)
 
 
@@ -376,7 +380,7 @@ def test_rope_and_llama_attention(lib, B, T, H, past):
     pos = torch.arange(past, past + T, dtype=torch.int64).unsqueeze(0).expand(B, T).contiguous().cuda()
     q_out = torch.empty(B * T, h, dtype=torch.bfloat16, device="cuda")
     rc = lib.seedmi_rope_kv_append(L.ptr(qkv), 3 * h, L.ptr(pos), L.ptr(cos_d), L.ptr(sin_d), L.ptr(q_out), h,
-                                   L.ptr(kc), L.ptr(vc), B, T, H, hd, tmax, past, L.stream_ptr())
+                                   L.ptr(kc), L.ptr(vc), B, T, H, hd, tmax, past, None, L.stream_ptr())
     L.check(rc, "rope_kv_append")
     torch.cuda.synchronize()
     qf = qkv[:, :h].float().view(B, T, H, hd).transpose(1, 2)
@@ -393,7 +397,7 @@ def test_rope_and_llama_attention(lib, B, T, H, past):
     out = torch.zeros(B * T, h, dtype=torch.bfloat16, device="cuda")
     scale = 1.0 / math.sqrt(hd)
     rc = lib.seedmi_llama_attention_bf16(L.ptr(q_out), h, L.ptr(kc), L.ptr(vc), L.ptr(out), h, B, T, H, hd, tmax, past, scale,
-                                         0, L.stream_ptr())
+                                         0, None, L.stream_ptr())
     L.check(rc, "llama_attention")
     torch.cuda.synchronize()
     kall = kc[:, :, :past + T].float()

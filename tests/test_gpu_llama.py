@@ -75,3 +75,16 @@ def test_llama_prefill_and_decode(golden_dir, B, T):
         assert (same[:, i] | ~confident[:, i] | ~alive).all(), f"greedy token differs at confident step {i}"
         alive &= same[:, i]
     print(f"[greedy B{B}] token agreement {same.float().mean().item():.3f}")
+
+
+def test_graph_decode_equals_eager_decode():
+    """The hipGraph-replayed decode loop (device-resident cache length) produces exactly the eager loop's tokens."""
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=9, norm_jitter=0.05)
+    ids = torch.randint(3, cfg.vocab, (3, 10), generator=torch.Generator().manual_seed(4)).cuda()
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=3, tmax=64)
+    eager, _ = eng.greedy_decode(ids, 9)
+    graphed = eng.greedy_decode_graph(ids, 9)
+    torch.cuda.synchronize()
+    assert torch.equal(eager, graphed)
+    assert eng.past_len == 10 + 8

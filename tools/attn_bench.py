@@ -15,8 +15,9 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B * N, 3 * C, device="cuda", generator=g).bfloat16()
 out = torch.empty(B * N, C, device="cuda", dtype=torch.bfloat16)
 flops = 4.0 * B * H * N * N * hd
-for trv in (1, 0):
-    L.check(lib.seedmi_set_option(b"attn_trv", trv), "opt")
+for trv in (2, 1, 0):
+    L.check(lib.seedmi_set_option(b"attn_vit", 1 if trv == 2 else 0), "opt")
+    L.check(lib.seedmi_set_option(b"attn_trv", min(trv, 1)), "opt")
     ts = []
     for i in range(8):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,3 +31,4 @@ for trv in (1, 0):
     med = sorted(ts)[len(ts) // 2]
     print(f"trv={trv}: {med * 1e3:.1f} us  {flops / med / 1e9:.1f} TFLOP/s", flush=True)
 lib.seedmi_set_option(b"attn_trv", 1)
+lib.seedmi_set_option(b"attn_vit", 1)

@@ -63,4 +63,18 @@ for name, N, K, epi in SHAPES:
         med = sorted(ts)[len(ts) // 2]
         line.append(f"PACKED R{rows}: {med * 1e3:7.1f} us {N * K * 2 / med / 1e6:7.0f} GB/s")
     L.check(lib.seedmi_set_option(b"skinny_rows", 0), "o")
+    Ap = torch.randn(((M + 15) // 16) * 16 * K, device="cuda", generator=g).bfloat16()   # fragment-major activations (timing only)
+    ts = []
+    for rnd in range(3):
+        for Wp in Wps:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.check(lib.seedmi_gemm_skinny_packed_bf16(M, N, K, L.ptr(Ap), K, L.ptr(Wp), L.ptr(R), N, epi, L.ptr(C), ldc,
+                                                       1, 0, L.stream_ptr()), "skinny_packed_a")
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd:
+                ts.append(e0.elapsed_time(e1))
+    med = sorted(ts)[len(ts) // 2]
+    line.append(f"PACKED W+A auto: {med * 1e3:7.1f} us {N * K * 2 / med / 1e6:7.0f} GB/s")
     print(" | ".join(line), flush=True)
