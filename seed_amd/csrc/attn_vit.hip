@@ -5,8 +5,8 @@
 // with every HBM->LDS transfer issued by LDS-DMA one stage ahead, so that nothing is ever waited for cold:
 //     K(i+1) is requested right before PV(i)   (the K image is free once every wave has finished QK^T(i)),
 //     V(i+1) right after PV(i)                 (lands during QK^T(i+1)),
-//     Q(i+1) fragments are prefetched into registers before V(i+1) is requested so that their wait does not
-//     drag V(i+1) along (vmcnt retires in order).
+//     Q(i+1) travels with K(i+1) into its own LDS image (no ordinary global loads inside the loop: vmcnt retires in
+//     order, and a register load younger than V(i+1)'s DMA would make its consumer wait for V as well).
 // K and V live in LDS row-major with UNPADDED 176-byte rows (11 x 16 B: an odd number of 16-byte slots keeps
 // ds_read_b128 / ds_read_b64_tr_b16 at <= 2-way conflicts) because LDS-DMA writes lane-linear images; the head
 // dim is padded to 96 on the register side instead: the Q fragment's last 16-byte chunk is zero, so whatever the
@@ -21,7 +21,8 @@ namespace {
 constexpr int VHD = 88, VCH = 11, VNKP = 288, VNT = 18, VKK = 9, VHT = 6;
 constexpr int VROWS = VNKP + 1;                         // one spill row for the 96-wide reads of the last key
 constexpr int VWAVES = 12;
-constexpr int VMAT_BYTES = VROWS * VHD * 2;             // 50,864 B per matrix image
+constexpr int VMAXT = 2;                                // q-tiles per wave: tiles w, w+12 (n <= 272 -> 17 tiles)
+constexpr int VMAT_BYTES = VROWS * VHD * 2;             // 50,864 B per matrix image (K, Q, V: 152.6 KB of LDS)
 
 struct VitAttnParams {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
@@ -37,23 +38,40 @@ SEEDMI_DEVINL void glds16v(const bf16_t* gptr, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <bool ROUND_S>
+SEEDMI_DEVINL void wait_vm(int leave) {                 // wave-uniform count of youngest VM ops allowed to stay in flight
+    switch (leave) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// NFIX > 0: the token count is a compile-time constant (257 for EVA-ViT-g at 224x224), so the dead-key handling of the
+// last key tiles costs nothing; NFIX == 0 keeps it a runtime value (the compiler then materialises 72 lane masks in
+// SGPRs, spills them and pays ~280 VALU per q-tile for it — measured; only odd test shapes take that path).
+template <bool ROUND_S, int NFIX>
 __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ksm = (bf16_t*)smem;
-    bf16_t* Vsm = (bf16_t*)(smem + VMAT_BYTES);
+    bf16_t* Qsm = (bf16_t*)(smem + VMAT_BYTES);
+    bf16_t* Vsm = (bf16_t*)(smem + 2 * VMAT_BYTES);
     const int tid = threadIdx.x;
     const int lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = p.n;
+    const int n = NFIX > 0 ? NFIX : p.n;
     const int total_chunks = n * VCH;
-    const int npieces = (total_chunks + 63) >> 6;                     // 1 KiB LDS-DMA pieces per matrix
-    const int my_pieces = (npieces - wave + VWAVES - 1) / VWAVES;     // pieces wave, wave+12, ... (wave-uniform)
+    const int npieces = (total_chunks + 63) >> 6;                     // 1 KiB LDS-DMA pieces per matrix (<= 48)
+    const int my_pieces = (npieces - wave + VWAVES - 1) / VWAVES;     // pieces wave, wave+8, ... (wave-uniform, <= 6)
     const int nqt = (n + 15) >> 4;
-    const int my_tiles = (nqt - wave + VWAVES - 1) / VWAVES;          // q-tiles wave, wave+12 (<= 2)
+    const int my_tiles = (nqt - wave + VWAVES - 1) / VWAVES;          // q-tiles wave, wave+8, wave+16
 
     // V image: rows >= n must hold finite values (they meet P == 0); zero the whole image once
-    for (int i = tid; i < VMAT_BYTES / 16; i += 64 * VWAVES) *(uint4*)(smem + VMAT_BYTES + 16 * i) = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < VMAT_BYTES / 16; i += 64 * VWAVES) *(uint4*)(smem + 2 * VMAT_BYTES + 16 * i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     auto stage = [&](const bf16_t* base, int ld, bf16_t* dst, int item) {
@@ -66,86 +84,105 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
             glds16v(src + (size_t)row * ld + 8 * c, (char*)dst + piece * 1024);
         }
     };
-    auto load_q = [&](bf16x8 (&qf)[2][3], int item) {
-        const int b = item / p.heads, h = item - b * p.heads;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int qrow = 16 * (wave + VWAVES * t) + li;
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                const int c0 = 32 * ks + 8 * g;
-                if (t < my_tiles && qrow < n && c0 < VHD) v = *(const uint4*)(p.Q + ((size_t)b * n + qrow) * p.ldq + h * VHD + c0);
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) w[i] = pack2bf(lo_bf(w[i]) * p.scale, hi_bf(w[i]) * p.scale);
-                qf[t][ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-            }
-        }
-    };
-    auto wait_vm = [&](int leave) {                                   // leave is wave-uniform and one of 0,3,4
-        if (leave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (leave == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else if (leave == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (leave == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    };
 
     int item = blockIdx.x;
     if (item >= p.items) return;
-    bf16x8 qf[2][3];
     stage(p.K, p.ldk, Ksm, item);
-    load_q(qf, item);
+    stage(p.Q, p.ldq, Qsm, item);
     stage(p.V, p.ldv, Vsm, item);
+    const float L2E = 1.4426950408889634f;
 
     for (;;) {
         const int b = item / p.heads, h = item - b * p.heads;
-        // ---- K(item) landed everywhere (only this wave's V pieces may still be in flight)
+        // ---- K(item), Q(item) landed everywhere (only this wave's V pieces may still be in flight)
         wait_vm(my_pieces);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- S^T = K Q^T and softmax per q-tile; P packed to bf16 MFMA operands and kept in registers
-        bf16x8 pf[2][VKK];
+        bf16x8 pf[VMAXT][VKK];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < VMAXT; ++t) {
             if (t < my_tiles) {
-                const int qrow = 16 * (wave + VWAVES * t) + li;
-                f32x4 s[VNT];
+                const int qt = wave + VWAVES * t;
+                bf16x8 qf[3];
 #pragma unroll
-                for (int kt = 0; kt < VNT; ++kt) {
-                    s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < 3; ++ks) {            // q * scale rounded to half; the 12th chunk (cols 88..95) is zero
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (32 * ks + 8 * g < VHD) v = *(const uint4*)(Qsm + (16 * qt + li) * VHD + 32 * ks + 8 * g);
+                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int ks = 0; ks < 3; ++ks) {
-                        const bf16x8 kf = *(const bf16x8*)(Ksm + (16 * kt + li) * VHD + 32 * ks + 8 * g);
-                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
-                    }
-                    if ((kt % 3) == 2) __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 4; ++i) w[i] = pack2bf(lo_bf(w[i]) * p.scale, hi_bf(w[i]) * p.scale);
+                    qf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
                 }
+                f32x4 s[VNT];
+                // software-pipelined K fragment reads: group gi+1 is requested before group gi's MFMAs are issued
+                bf16x8 fk0[6], fk1[6];
+                auto ldk = [&](bf16x8 (&f)[6], int grp) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int ks = 0; ks < 3; ++ks)
+                            f[3 * u + ks] = *(const bf16x8*)(Ksm + (16 * (2 * grp + u) + li) * VHD + 32 * ks + 8 * g);
+                };
+                auto mmk = [&](bf16x8 (&f)[6], int grp) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        s[2 * grp + u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 3; ++ks)
+                            s[2 * grp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[3 * u + ks], qf[ks], s[2 * grp + u], 0, 0, 0);
+                    }
+                };
+                ldk(fk0, 0);
+#pragma unroll
+                for (int grp = 0; grp < VNT / 2; ++grp) {
+                    if (grp & 1) {
+                        if (grp + 1 < VNT / 2) ldk(fk0, grp + 1);
+                        mmk(fk1, grp);
+                    } else {
+                        if (grp + 1 < VNT / 2) ldk(fk1, grp + 1);
+                        mmk(fk0, grp);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // softmax over keys {16*kt + 4g + r}: S rounded to half like the reference's matmul output
                 float mx = -INFINITY;
 #pragma unroll
-                for (int kt = 0; kt < VNT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = ROUND_S ? rbf(s[kt][r]) : s[kt][r];
-                        if (16 * kt + 15 >= n) v = (16 * kt + 4 * g + r >= n) ? -INFINITY : v;
-                        s[kt][r] = v;
-                        mx = fmaxf(mx, v);
+                for (int kt = 0; kt < VNT; ++kt) {
+                    float v0 = s[kt][0], v1 = s[kt][1], v2 = s[kt][2], v3 = s[kt][3];
+                    if (ROUND_S) {
+                        const uint32_t w0 = pack2bf(v0, v1), w1 = pack2bf(v2, v3);
+                        v0 = lo_bf(w0); v1 = hi_bf(w0); v2 = lo_bf(w1); v3 = hi_bf(w1);
                     }
+                    const int live = n - 16 * kt;            // keys of this tile that exist (compile-time when NFIX > 0)
+                    if (live <= 0) {
+                        v0 = v1 = v2 = v3 = -INFINITY;
+                    } else if (live < 16) {
+                        const int k0 = 4 * g;
+                        v0 = (k0 + 0 >= live) ? -INFINITY : v0;
+                        v1 = (k0 + 1 >= live) ? -INFINITY : v1;
+                        v2 = (k0 + 2 >= live) ? -INFINITY : v2;
+                        v3 = (k0 + 3 >= live) ? -INFINITY : v3;
+                    }
+                    s[kt][0] = v0; s[kt][1] = v1; s[kt][2] = v2; s[kt][3] = v3;
+                    mx = fmaxf(fmaxf(mx, v0), fmaxf(v1, fmaxf(v2, v3)));
+                }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float nmx = -mx * L2E;
                 float sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < VNT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = __expf(s[kt][r] - mx);
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], L2E, nmx));
                         s[kt][r] = e;
                         sum += e;
                     }
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
-                const float inv = 1.0f / sum;
+                const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                 for (int kk = 0; kk < VKK; ++kk) {
                     uint4 pw;
@@ -155,34 +192,50 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
                     pw.w = pack2bf(s[2 * kk + 1][2] * inv, s[2 * kk + 1][3] * inv);
                     pf[t][kk] = __builtin_bit_cast(bf16x8, pw);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
-        // ---- V(item) landed; every wave is done with K(item)
+        // ---- V(item) landed; every wave is done with K(item) and Q(item)
         wait_vm(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const int next = item + gridDim.x;
         const bool more = next < p.items;
-        if (more) stage(p.K, p.ldk, Ksm, next);
+        if (more) {
+            stage(p.K, p.ldk, Ksm, next);
+            stage(p.Q, p.ldq, Qsm, next);
+        }
 
         // ---- O^T = V^T P^T (hardware transpose read of the row-major V image), store
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < VMAXT; ++t) {
             if (t < my_tiles) {
                 f32x4 o[VHT];
 #pragma unroll
                 for (int nn = 0; nn < VHT; ++nn) o[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < VKK; ++kk) {
+                bf16x8 fv0[VHT], fv1[VHT];
+                auto ldv = [&](bf16x8 (&f)[VHT], int kk) {
 #pragma unroll
                     for (int nn = 0; nn < VHT; ++nn) {
                         const bf16_t* vp = Vsm + (32 * kk + 4 * g + (li >> 2)) * VHD + 16 * nn + 4 * (li & 3);
                         const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
                         const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 16 * VHD));
                         const uint2 lo = __builtin_bit_cast(uint2, a), hi = __builtin_bit_cast(uint2, c);
-                        const uint4 vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf[t][kk], o[nn], 0, 0, 0);
+                        f[nn] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    }
+                };
+                ldv(fv0, 0);
+#pragma unroll
+                for (int kk = 0; kk < VKK; ++kk) {
+                    if (kk & 1) {
+                        if (kk + 1 < VKK) ldv(fv0, kk + 1);
+#pragma unroll
+                        for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pf[t][kk], o[nn], 0, 0, 0);
+                    } else {
+                        if (kk + 1 < VKK) ldv(fv1, kk + 1);
+#pragma unroll
+                        for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pf[t][kk], o[nn], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -203,7 +256,6 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
             }
         }
         if (!more) break;
-        load_q(qf, next);                                          // before V(next): its wait must not include V(next)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                              // every wave is done with V(item)
         stage(p.V, p.ldv, Vsm, next);
@@ -234,16 +286,20 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     const int grid = p.items < n_cu ? p.items : n_cu;
-    constexpr int lds = 2 * VMAT_BYTES;
+    constexpr int lds = 3 * VMAT_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)attn_vit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_vit_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (round_scores)
-        hipLaunchKernelGGL(attn_vit_kernel<true>, dim3(grid), dim3(64 * VWAVES), lds, (hipStream_t)stream, p);
+    const dim3 blk(64 * VWAVES);
+    if (round_scores && nq == 257)
+        hipLaunchKernelGGL((attn_vit_kernel<true, 257>), dim3(grid), blk, lds, (hipStream_t)stream, p);
+    else if (round_scores)
+        hipLaunchKernelGGL((attn_vit_kernel<true, 0>), dim3(grid), blk, lds, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(attn_vit_kernel<false>, dim3(grid), dim3(64 * VWAVES), lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((attn_vit_kernel<false, 0>), dim3(grid), blk, lds, (hipStream_t)stream, p);
     return seedmi_check_launch("attn_vit");
 }
