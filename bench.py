@@ -78,9 +78,18 @@ def qkv_gemm_roofline(batch):
     avg_ms, med_ms = time_kernel_events(run, 20)
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm128_kernel<BIAS> (ViT QKV: M=%d K=%d N=%d)" % (M, K, N),
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_qkv_gemm256.json")
+    if batch == 256 and os.path.exists(pmc):
+        # HBM-side bytes per launch from rocprofv3 --pmc passes of this same kernel/shape (collected offline, one counter
+        # group per pass; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, both in KiB)
+        d = json.load(open(pmc))
+        traffic = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+        traffic_src = "profiles/r01_pmc_qkv_gemm256.json"
+    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS>, persistent (ViT QKV: M=%d K=%d N=%d)" % (M, K, N),
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": 2.0 * (M * K + N * K + M * N),
             "flops_per_launch": flops, "avg_launch_ms": round(avg_ms, 4), "median_launch_ms": round(med_ms, 4)}
 
 
@@ -166,10 +175,13 @@ def main():
     del sd
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     images = torch.randn(B, 3, 224, 224, device="cuda", generator=g).bfloat16()      # resident in HBM
+    # the synthetic codebook is calibrated on a rank-independent image set so every rank quantises identically
+    gc = torch.Generator(device="cuda").manual_seed(4321)
+    calib = torch.randn(8, 3, 224, 224, device="cuda", generator=gc).bfloat16()
     taps = {}
-    eng.encode(images[:8], taps)
+    eng.encode(calib, taps)
     eng.set_codebook(calibrate_codebook(taps["z"].float().cpu(), cfg.n_embed, seed=7))
-    del taps
+    del taps, calib
 
     def step():
         ids = eng.encode(images)

@@ -31,7 +31,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A tile + W tile
-constexpr int GROUP_M = 8;
+int g_group_m = 8;                 // seedmi_set_option("gemm_group_m", v): m-tiles per L2 tile group
 
 struct GemmParams {
     int M, N, K;
@@ -41,6 +41,7 @@ struct GemmParams {
     const bf16_t* R; int ldr;
     bf16_t* C; int ldc;
     int tiles_m, tiles_n;
+    int group_m;                // m-tiles walked per group of the tile order (L2 locality)
     int row_group, row_extra;   // patch-embed: out_row = m + (m / row_group) * row_extra + row_extra ; res_row = m % row_group + row_extra
 };
 
@@ -72,6 +73,22 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             for (int i = 0; i < 16; ++i) if (nb + i < p.N) bias[i] = bf2f(p.bias[nb + i]);
         }
     }
+    // residual / pos_embed rows of ALL the lane's rows are requested up front: one exposed HBM latency per tile instead
+    // of one per row (the per-row form serialised 8 round trips and cost the proj GEMM 25 %)
+    uint4 rr[MT][2];
+    if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_PATCH_EMBED) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int m = min(mrow0 + 16 * mi + li, p.M - 1);
+            int res_row = m;
+            if (EPI == EPI_PATCH_EMBED) res_row = m - (m / p.row_group) * p.row_group + p.row_extra;
+            const bf16_t* rp = p.R + (size_t)res_row * p.ldr + nb;
+            if (full) {
+                rr[mi][0] = *(const uint4*)rp;
+                rr[mi][1] = *(const uint4*)(rp + 8);
+            }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
         const int m = mrow0 + 16 * mi + li;
@@ -98,8 +115,8 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             }
             const bf16_t* rp = p.R + (size_t)res_row * p.ldr + nb;
             if (full) {
-                const uint4 r0 = *(const uint4*)rp;
-                const uint4 r1 = *(const uint4*)(rp + 8);
+                const uint4 r0 = rr[mi][0];
+                const uint4 r1 = rr[mi][1];
                 const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -146,10 +163,10 @@ SEEDMI_DEVINL void tile_of_block(const GemmParams& p, int& tm, int& tn) {
     const int q = nt >> 3, r = nt & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int gsize = GROUP_M * p.tiles_n;
+    const int gsize = p.group_m * p.tiles_n;
     const int gid = t / gsize;
-    const int first_m = gid * GROUP_M;
-    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int first_m = gid * p.group_m;
+    const int gm = min(p.tiles_m - first_m, p.group_m);
     const int in_g = t - gid * gsize;
     tm = first_m + in_g % gm;
     tn = in_g / gm;
@@ -308,10 +325,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     int offA[2][2], offW[2][2];
     // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
     auto set_tile = [&](int t) {
-        const int gsize = GROUP_M * p.tiles_n;
+        const int gsize = p.group_m * p.tiles_n;
         const int gid = t / gsize;
-        const int first_m = gid * GROUP_M;
-        const int gm = min(p.tiles_m - first_m, GROUP_M);
+        const int first_m = gid * p.group_m;
+        const int gm = min(p.tiles_m - first_m, p.group_m);
         const int in_g = t - gid * gsize;
         m0 = (first_m + in_g % gm) * B2;
         n0 = (in_g / gm) * B2;
@@ -504,10 +521,10 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmParams p) {
     int offA[2][2], offW[2][2];
     // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
     auto set_tile = [&](int t) {
-        const int gsize = GROUP_M * p.tiles_n;
+        const int gsize = p.group_m * p.tiles_n;
         const int gid = t / gsize;
-        const int first_m = gid * GROUP_M;
-        const int gm = min(p.tiles_m - first_m, GROUP_M);
+        const int first_m = gid * p.group_m;
+        const int gm = min(p.tiles_m - first_m, p.group_m);
         const int in_g = t - gid * gsize;
         m0 = (first_m + in_g % gm) * B2;
         n0 = (in_g / gm) * B2;
@@ -741,6 +758,10 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
+    if (key && !strcmp(key, "gemm_group_m") && value >= 1 && value <= 64) {
+        g_group_m = value;
+        return SEEDMI_OK;
+    }
     if (key && !strcmp(key, "gemm_persist") && (value == 0 || value == 1)) {
         g_gemm_persist = value;
         return SEEDMI_OK;
@@ -781,6 +802,7 @@ extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, con
     p.C = (bf16_t*)C; p.ldc = ldc;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
+    p.group_m = g_group_m;
     p.row_group = row_group > 0 ? row_group : 1;
     p.row_extra = row_extra;
     hipStream_t s = (hipStream_t)stream;

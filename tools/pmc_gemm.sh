@@ -8,7 +8,7 @@ P2="SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_
 P3="FETCH_SIZE"
 P4="WRITE_SIZE"
 P5="TCC_HIT_sum TCC_MISS_sum"
-for cfg in "256 65792 1408 6144" "256 65792 4224 1408" "128 65792 4224 1408"; do
+for cfg in "256 65792 4224 1408" "256 65792 1408 6144"; do
   set -- $cfg; tag="v$1_N$3_K$4"
   i=0
   for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
