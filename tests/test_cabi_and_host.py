@@ -98,3 +98,38 @@ def test_data_parallel_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_dp_pretokenizer_tool_shards_and_format(tmp_path):
+    """seed_amd/tools/extract_image_ids.py: every rank writes its own contiguous shard as tar members of pickled
+    {'image_ids','text','metadata'} (the reference tool's on-disk format); the union over ranks is the whole set."""
+    import pickle
+    import tarfile
+    from seed_amd.tools.extract_image_ids import run
+    items = list(range(23))
+
+    def load(i):
+        return torch.full((3, 4, 4), float(i)), f"caption {i}", {"index": i}
+
+    def fake_encode(x):                                   # a pure per-image map, like TokenizerEngine.encode
+        return (x[:, 0, 0, 0].long()[:, None] * 100 + torch.arange(32)[None])
+
+    total = 0
+    for rank in range(3):
+        total += run(fake_encode, items, load, str(tmp_path), rank, 3, batch_size=4, device="cpu", maxcount=5, log=None)
+    assert total == 23
+    seen = {}
+    for rank in range(3):
+        d = tmp_path / f"part-{rank:04d}"
+        for tar in sorted(os.listdir(d)):
+            with tarfile.open(d / tar) as tf:
+                members = tf.getmembers()
+                assert len(members) <= 5
+                for m in members:
+                    s = pickle.loads(tf.extractfile(m).read())
+                    assert set(s) == {"image_ids", "text", "metadata"} and len(s["image_ids"]) == 32
+                    i = s["metadata"]["index"]
+                    assert s["image_ids"][0] == i * 100 and s["text"] == f"caption {i}" and m.name == f"{i:09d}.pkl"
+                    seen[i] = rank
+    assert sorted(seen) == items
+    assert [seen[i] for i in items] == sorted(seen[i] for i in items)        # contiguous shards in rank order

@@ -109,3 +109,31 @@ def test_clip_transform_fallback_matches_definition():
     ref = torch.from_numpy(np.asarray(img.resize((224, 224), resample=2))).permute(2, 0, 1).float() / 255
     ref = (ref - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
     assert torch.allclose(t, ref, atol=1e-6)
+
+
+def test_image_token_splice_and_parse_roundtrip():
+    """Direct id arithmetic == the reference's '<img_%05d>' string round trip (scripts/seed_llama_inference_8B.py:99-105)."""
+    from seed_amd import splice
+    boi, eoi = 32000 + 8192, 32000 + 8193
+    ids = torch.randint(0, 8192, (2, 32), generator=torch.Generator().manual_seed(0))
+    span = splice.image_span(ids, boi, eoi)
+    assert span.shape == (2, 34) and (span[:, 0] == boi).all() and (span[:, -1] == eoi).all()
+    assert torch.equal(span[:, 1:-1] - splice.IMAGE_ID_SHIFT, ids)
+    text_a = torch.randint(3, 32000, (2, 5))
+    text_b = torch.randint(3, 32000, (2, 7))
+    prompt = splice.splice_prompt([text_a, span, text_b])
+    assert prompt.shape == (2, 5 + 34 + 7)
+    gen = torch.cat((text_b[0], span[0], text_a[0]))
+    text, img = splice.parse_generated(gen, boi, eoi)
+    assert torch.equal(text, text_b[0]) and torch.equal(img, ids[:1])
+    text, img = splice.parse_generated(text_a[0], boi, eoi)
+    assert img is None and torch.equal(text, text_a[0])
+
+
+def test_top_p_sampling_rule():
+    from seed_amd import splice
+    logits = torch.log(torch.tensor([[0.4, 0.3, 0.2, 0.1], [0.97, 0.01, 0.01, 0.01]]))
+    g = torch.Generator().manual_seed(0)
+    draws = torch.cat([splice.sample_top_p(logits, top_p=0.5, generator=g) for _ in range(400)], dim=1)
+    assert set(draws[0].tolist()) <= {0, 1} and set(draws[1].tolist()) == {0}     # nucleus {0.4,0.3} / {0.97}
+    assert 0.45 < (draws[0] == 0).float().mean() < 0.70                           # 0.4/0.7 = 0.571
