@@ -160,9 +160,10 @@ int run_phase(const Part& p, int phase) {
 constexpr int SPLIT_MIN_BATCH = 32;      // below this the kernels are too small for a second stream to help
 int g_tok_streams = 2;                    // seedmi_set_option("tokenize_streams", 1|2)
 
+constexpr int MAX_PARTS = 4;
 struct ForkJoin {
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t side[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
     int device = -1;
 };
 thread_local ForkJoin g_fj;
@@ -170,26 +171,30 @@ thread_local ForkJoin g_fj;
 int ensure_forkjoin() {
     int dev = 0;
     HIPCK(hipGetDevice(&dev));
-    if (g_fj.side && g_fj.device == dev) return SEEDMI_OK;
-    HIPCK(hipStreamCreateWithFlags(&g_fj.side, hipStreamNonBlocking));
+    if (g_fj.fork && g_fj.device == dev) return SEEDMI_OK;
     HIPCK(hipEventCreateWithFlags(&g_fj.fork, hipEventDisableTiming));
-    HIPCK(hipEventCreateWithFlags(&g_fj.join, hipEventDisableTiming));
+    for (int i = 0; i < MAX_PARTS - 1; ++i) {
+        HIPCK(hipStreamCreateWithFlags(&g_fj.side[i], hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&g_fj.join[i], hipEventDisableTiming));
+    }
     g_fj.device = dev;
     return SEEDMI_OK;
 }
 
-size_t total_ws(const seedmi_tokenizer_weights_t* w, int batch) {
-    if (g_tok_streams >= 2 && batch >= SPLIT_MIN_BATCH) {
-        const int b0 = (batch + 1) / 2;
-        return carve(w, b0, nullptr).bytes + carve(w, batch - b0, nullptr).bytes;
-    }
-    return carve(w, batch, nullptr).bytes;
+int n_parts(int batch) { return (g_tok_streams >= 2 && batch >= SPLIT_MIN_BATCH) ? g_tok_streams : 1; }
+int part_size(int batch, int nparts, int i) { return batch / nparts + (i < batch % nparts ? 1 : 0); }
+
+size_t ws_for(const seedmi_tokenizer_weights_t* w, int batch, int nparts) {
+    size_t total = 0;
+    for (int i = 0; i < nparts; ++i) total += carve(w, part_size(batch, nparts, i), nullptr).bytes;
+    return total;
 }
+size_t total_ws(const seedmi_tokenizer_weights_t* w, int batch) { return ws_for(w, batch, n_parts(batch)); }
 
 }  // namespace
 
 int seedmi_tokenizer_set_streams(int n) {
-    if (n != 1 && n != 2) return SEEDMI_E_SHAPE;
+    if (n < 1 || n > MAX_PARTS) return SEEDMI_E_SHAPE;
     g_tok_streams = n;
     return SEEDMI_OK;
 }
@@ -197,10 +202,12 @@ int seedmi_tokenizer_set_streams(int n) {
 extern "C" size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int batch) {
     if (!w || batch <= 0) return 0;
     // sized for either mode so a later seedmi_set_option("tokenize_streams", ...) cannot under-allocate
-    const size_t one = carve(w, batch, nullptr).bytes;
-    const int b0 = (batch + 1) / 2;
-    const size_t two = batch >= 2 ? carve(w, b0, nullptr).bytes + carve(w, batch - b0, nullptr).bytes : one;
-    return one > two ? one : two;
+    size_t best = 0;
+    for (int np = 1; np <= MAX_PARTS && np <= batch; ++np) {
+        const size_t b = ws_for(w, batch, np);
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch,
@@ -223,15 +230,15 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
     const int grid = w->img_size / w->patch;
     const size_t NT = (size_t)grid * grid + 1;
     const size_t img_bytes = (size_t)3 * w->img_size * w->img_size * (images_fp32 ? 4 : 2);
-    const bool split = g_tok_streams >= 2 && batch >= SPLIT_MIN_BATCH;
-    const int nparts = split ? 2 : 1;
-    Part parts[2];
+    const int nparts = n_parts(batch);
+    const bool split = nparts > 1;
+    Part parts[MAX_PARTS];
     int b_begin = 0;
     char* ws = (char*)workspace;
     for (int i = 0; i < nparts; ++i) {
         Part& p = parts[i];
         p.w = w;
-        p.B = split ? (i == 0 ? (batch + 1) / 2 : batch - (batch + 1) / 2) : batch;
+        p.B = part_size(batch, nparts, i);
         p.images = (const char*)images + (size_t)b_begin * img_bytes;
         p.images_fp32 = images_fp32;
         p.ids = (long long*)ids_i64 + (size_t)b_begin * w->n_query;
@@ -245,16 +252,18 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
     }
     if (split) {
         CK(ensure_forkjoin());
-        parts[1].s = g_fj.side;
         HIPCK(hipEventRecord(g_fj.fork, (hipStream_t)stream));
-        HIPCK(hipStreamWaitEvent(g_fj.side, g_fj.fork, 0));
+        for (int i = 1; i < nparts; ++i) {
+            parts[i].s = g_fj.side[i - 1];
+            HIPCK(hipStreamWaitEvent(g_fj.side[i - 1], g_fj.fork, 0));
+        }
     }
     const int np = n_phases(w);
     for (int ph = 0; ph < np; ++ph)
         for (int i = 0; i < nparts; ++i) CK(run_phase(parts[i], ph));
-    if (split) {
-        HIPCK(hipEventRecord(g_fj.join, g_fj.side));
-        HIPCK(hipStreamWaitEvent((hipStream_t)stream, g_fj.join, 0));
+    for (int i = 1; i < nparts; ++i) {
+        HIPCK(hipEventRecord(g_fj.join[i - 1], g_fj.side[i - 1]));
+        HIPCK(hipStreamWaitEvent((hipStream_t)stream, g_fj.join[i - 1], 0));
     }
     return SEEDMI_OK;
 }
