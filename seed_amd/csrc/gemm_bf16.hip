@@ -19,6 +19,7 @@
 // Workgroups are remapped so that each XCD (private 4 MiB L2) walks a contiguous range of tiles in
 // grouped (8 m-tiles x all n-tiles) order.
 #include <string.h>
+#include <type_traits>
 #include "common.h"
 #include "seedmi_internal.h"
 
@@ -31,6 +32,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A tile + W tile
+int g_gemm_ablate = 0;             // seedmi_set_option("gemm_ablate", mask): timing-only ablations of the 255 kernel
 int g_group_m = 8;                 // seedmi_set_option("gemm_group_m", v): m-tiles per L2 tile group
 
 struct GemmParams {
@@ -494,6 +496,196 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
 }
 
+// ABL (timing ablations only, results are wrong): 1 = no fragment reads in the loop, 2 = no LDS-DMA in the loop,
+// 4 = no barrier / vmcnt wait in the loop
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, g = lane >> 4;
+
+    // ---- persistent tile walk: the launch holds one workgroup per CU; workgroup b (XCD b % 8) takes every
+    //      (workgroups-on-that-XCD)-th tile of its XCD's contiguous chunk of the grouped tile order, so the tiles
+    //      resident on an XCD at any time are neighbours sharing A / W panels in its L2.
+    const int nt = p.tiles_m * p.tiles_n;
+    int t_cur, t_end, t_stride;
+    {
+        const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+        const int cs = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
+        t_stride = ((int)gridDim.x + 7 - xcd) >> 3;
+        t_cur = cs + idx;
+        t_end = cs + q + (xcd < r ? 1 : 0);
+    }
+    if (t_cur >= t_end) return;                                        // uniform for the whole workgroup
+
+    int m0 = 0, n0 = 0;
+    int offA[2][2], offW[2][2];
+    // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
+    auto set_tile = [&](int t) {
+        const int gsize = p.group_m * p.tiles_n;
+        const int gid = t / gsize;
+        const int first_m = gid * p.group_m;
+        const int gm = min(p.tiles_m - first_m, p.group_m);
+        const int in_g = t - gid * gsize;
+        m0 = (first_m + in_g % gm) * B2;
+        n0 = (in_g / gm) * B2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
+                const int cs = lane & 7;
+                offA[h][j] = min(((ABL & 8) ? 0 : m0) + row, p.M - 1) * p.lda + 8 * (cs ^ swzA(row));
+                offW[h][j] = min(((ABL & 8) ? 0 : n0) + row, p.N - 1) * p.ldw + 8 * (cs ^ swzW(row));
+            }
+    };
+    // ---- fragment read bases (byte offsets inside a K-tile buffer); tile index adds an immediate
+    //   A: row = 16*mi + li inside half wm   (swizzle depends on li only)
+    //   W: row = 64*wn + 16*(li>>2) + 4*ni + (li&3) inside the 256-row tile, half wn>>1 (swizzle independent of ni)
+    const int rowW0 = 64 * wn + 16 * (li >> 2) + (li & 3);
+    const int rdA0 = wm * HALF_BYTES + li * 128 + ((g ^ swzA(li)) << 4);
+    const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((g ^ swzW(rowW0)) << 4);
+
+    f32x4 acc[8][4];
+    const int nk = p.K / BK;
+    auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
+        char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
+        const int k0 = (ABL & 8) ? 0 : kt * BK;            // ablation 8: every K-tile re-reads the same (L2-hot) 64 KiB
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(p.A + (size_t)(offA[h][j] + k0), base + h * HALF_BYTES + j * 1024);
+    };
+    auto stageW = [&](int kt) {
+        char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
+        const int k0 = (ABL & 8) ? 0 : kt * BK;            // ablation 8: every K-tile re-reads the same (L2-hot) 64 KiB
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(p.W + (size_t)(offW[h][j] + k0), base + h * HALF_BYTES + j * 1024);
+    };
+
+    // prologue loads of a tile: K-tiles 0 and 1 (A and W each)
+    auto issue_prologue = [&]() {
+        stageA(0);
+        stageW(0);
+        if (nk > 1) { stageA(1); stageW(1); }
+    };
+    set_tile(t_cur);
+    issue_prologue();
+
+    // "free-running" schedule: ONE barrier per K-tile.  Fragments are double-buffered by k-step (32 deep): while the 32
+    // MFMAs of one k-step issue from one register set, the 12 ds_read_b128 of the next k-step fill the other.  The barrier
+    // sits after the last LDS read of K-tile t; behind it the wave requests the LDS-DMA of K-tile t+2 into the buffer just
+    // vacated and the first fragments of K-tile t+1 (whose DMA was requested a whole K-tile earlier, so vmcnt(0) at the
+    // barrier costs nothing).  No stagger: the two waves of a SIMD drift apart by themselves and share the matrix pipe.
+    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
+    auto rd = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4], const char* sb, int ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fw[t] = *(const bf16x8*)(sb + ((rdW0 ^ (ks << 6)) + t * 512));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fa[t] = *(const bf16x8*)(sb + ((rdA0 ^ (ks << 6)) + t * 2048));
+    };
+    auto mm = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+    };
+    // pin the issue order inside a k-step: 4 MFMAs, then 1-2 of the next k-step's fragment reads, and so on, so that the
+    // wait in front of the first MFMA covers only the fragments requested a whole k-step ago
+    auto interleave = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    };
+    for (;;) {
+    const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // K-tile 0 complete (the up-to-8 youngest VM ops are K-tile 1's LDS-DMA or the previous tile's epilogue stores)
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    SEEDMI_SCHED_FENCE();
+    rd(fa0, fw0, smem, 0);
+    if (ABL & 1) rd(fa1, fw1, smem, 1);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + (kt & 1) * KT_BYTES;
+        // ---- k-step 0 of K-tile kt issues while k-step 1's fragments are read
+        if (!(ABL & 1)) rd(fa1, fw1, sb, 1);
+        mm(fa0, fw0);
+        interleave();
+        SEEDMI_SCHED_FENCE();
+        // ---- all LDS reads of K-tile kt are complete; K-tile kt+1 has landed (requested one K-tile ago)
+        if (!(ABL & 4)) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        SEEDMI_SCHED_FENCE();
+        if (ABL & 16) {
+            // branch-free request of K-tile kt+2 (a dead request lands in the 1 KiB scratch block), spread between the MFMAs
+            const bool live = kt + 2 < nk;
+            char* base = live ? smem + (kt & 1) * KT_BYTES + wave * 2048 : smem + 2 * KT_BYTES;
+            const int hs = live ? HALF_BYTES : 0, js = live ? 1024 : 0, ws = live ? 2 * HALF_BYTES : 0;
+            const int k0 = live ? (kt + 2) * BK : 0;
+            rd(fa0, fw0, smem + ((kt + 1) & 1) * KT_BYTES, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    glds16(p.A + (size_t)(offA[h][j] + k0), base + h * hs + j * js);
+                    glds16(p.W + (size_t)(offW[h][j] + k0), base + ws + h * hs + j * js);
+                }
+            mm(fa1, fw1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        } else {
+            if (!(ABL & 2) && kt + 2 < nk) { stageA(kt + 2); stageW(kt + 2); }      // into the buffer K-tile kt just vacated
+            if (!(ABL & 1)) rd(fa0, fw0, smem + ((kt + 1) & 1) * KT_BYTES, 0);     // (after the last K-tile: stale LDS, unused)
+            mm(fa1, fw1);
+            interleave();
+        }
+        SEEDMI_SCHED_FENCE();
+    }
+    if (ABL & 16) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave has issued its last LDS read
+    SEEDMI_SCHED_FENCE();
+
+    // every LDS read of this tile is done: start the next tile's prologue loads now so that their latency (and the
+    // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
+    const int t_next = t_cur + t_stride;
+    const bool more = t_next < t_end;
+    if (more) {
+        set_tile(t_next);
+        issue_prologue();
+    }
+    gemm_epilogue<EPI, 8>(p, acc, em0 + 128 * wm, en0 + 64 * wn + 16 * g, li);
+    if (!more) break;
+    t_cur = t_next;
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -709,6 +901,46 @@ int launch_gemm256(GemmParams p, hipStream_t stream) {
 }
 
 template <int EPI>
+int launch_gemm256f(GemmParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256f_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES);
+        attr_set = true;
+    }
+    p.tiles_m = (p.M + B2 - 1) / B2;
+    p.tiles_n = (p.N + B2 - 1) / B2;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int nt = p.tiles_m * p.tiles_n;
+    const int grid = (g_gemm_persist && nt > n_cu) ? n_cu : nt;
+    if (EPI == EPI_BIAS && g_gemm_ablate) {
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES + 1024);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * KT_BYTES + 1024, stream, p);
+        };
+        switch (g_gemm_ablate) {
+            case 1: go(gemm256f_kernel<EPI_BIAS, 1>); break;
+            case 2: go(gemm256f_kernel<EPI_BIAS, 2>); break;
+            case 3: go(gemm256f_kernel<EPI_BIAS, 3>); break;
+            case 4: go(gemm256f_kernel<EPI_BIAS, 4>); break;
+            case 6: go(gemm256f_kernel<EPI_BIAS, 6>); break;
+            case 8: go(gemm256f_kernel<EPI_BIAS, 8>); break;
+            case 16: go(gemm256f_kernel<EPI_BIAS, 16>); break;
+            case 24: go(gemm256f_kernel<EPI_BIAS, 24>); break;
+            case 12: go(gemm256f_kernel<EPI_BIAS, 12>); break;
+            default: go(gemm256f_kernel<EPI_BIAS, 7>); break;
+        }
+        return seedmi_check_launch("gemm256f(ablation)");
+    }
+    hipLaunchKernelGGL(gemm256f_kernel<EPI>, dim3(grid), dim3(512), 2 * KT_BYTES, stream, p);
+    return seedmi_check_launch("gemm256f");
+}
+
+template <int EPI>
 int launch_gemm256x(GemmParams p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -746,7 +978,8 @@ int g_gemm_variant = 0;      // 0 = auto, 128 / 256 = force a kernel (seedmi_set
 template <int EPI>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     const bool big = p.M >= 1024 && p.N >= 256;
-    if (g_gemm_variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
+    if (g_gemm_variant == 232) return launch_gemm256x<EPI>(p, s);
+    if (g_gemm_variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves          // 256x256 tile on v_mfma_f32_32x32x16_bf16
     const bool use256 = g_gemm_variant == 256 || (g_gemm_variant == 0 && big && SEEDMI_GEMM256_DEFAULT);
     return use256 ? launch_gemm256<EPI>(p, s) : launch_gemm128<EPI>(p, s);
 }
@@ -754,12 +987,16 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int seedmi_set_option(const char* key, int value) {
-    if (key && !strcmp(key, "gemm") && (value == 0 || value == 128 || value == 256 || value == 232)) {
+    if (key && !strcmp(key, "gemm") && (value == 0 || value == 128 || value == 256 || value == 232 || value == 255)) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
     if (key && !strcmp(key, "gemm_group_m") && value >= 1 && value <= 64) {
         g_group_m = value;
+        return SEEDMI_OK;
+    }
+    if (key && !strcmp(key, "gemm_ablate") && value >= 0 && value <= 31) {
+        g_gemm_ablate = value;
         return SEEDMI_OK;
     }
     if (key && !strcmp(key, "gemm_persist") && (value == 0 || value == 1)) {

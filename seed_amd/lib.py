@@ -105,6 +105,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # tuning knobs for experiments: SEEDMI_OPTIONS="gemm_persist=0,gemm_group_m=4" (same keys as seedmi_set_option)
+    for kv in filter(None, os.environ.get("SEEDMI_OPTIONS", "").split(",")):
+        key, _, val = kv.partition("=")
+        if lib.seedmi_set_option(key.strip().encode(), int(val)) != 0:
+            raise SeedmiError(f"SEEDMI_OPTIONS: bad option {kv!r}: {lib.seedmi_last_error().decode(errors='replace')}")
     return lib
 
 

@@ -69,7 +69,7 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[128, 256, 232], ids=["gemm128", "gemm256", "gemm256x32"])
+@pytest.fixture(params=[128, 256, 232, 255], ids=["gemm128", "gemm256", "gemm256x32", "gemm256free"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (128x128 two-barrier and 256x256 staggered deep pipeline)."""
     L.check(lib.seedmi_set_option(b"gemm", request.param), "set_option")

@@ -12,10 +12,15 @@ from seed_amd import lib as L  # noqa: E402
 
 lib = L.load()
 B = int(os.environ.get("B", "256"))
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "128,256,255").split(",")]
 SHAPES = [("qkv", B * 257, 4224, 1408, L.EPI_BIAS), ("proj", B * 257, 1408, 1408, L.EPI_BIAS_RESIDUAL),
           ("fc1", B * 257, 6144, 1408, L.EPI_BIAS_GELU), ("fc2", B * 257, 1408, 6144, L.EPI_BIAS_RESIDUAL),
           ("patch", B * 256, 1408, 640, L.EPI_BIAS), ("cross_kv", B * 257, 1536, 1408, L.EPI_BIAS),
           ("qf_ffn1", B * 32, 3072, 768, L.EPI_BIAS_GELU)]
+if os.environ.get("EXTRA"):                                 # epilogue-free twins and a long-K square, to separate loop from epilogue
+    SHAPES = [("square8k", 8192, 8192, 8192, L.EPI_BIAS), ("proj_biasonly", B * 257, 1408, 1408, L.EPI_BIAS),
+              ("fc1_biasonly", B * 257, 6144, 1408, L.EPI_BIAS), ("fc2_biasonly", B * 257, 1408, 6144, L.EPI_BIAS),
+              ("square4k", 4096, 4096, 4096, L.EPI_BIAS), ("k16k", 4096, 4096, 16384, L.EPI_BIAS)]
 g = torch.Generator(device="cuda").manual_seed(0)
 res = {}
 for name, M, N, K, epi in SHAPES:
@@ -24,11 +29,10 @@ for name, M, N, K, epi in SHAPES:
     bias = (torch.randn(N, device="cuda", generator=g) * 0.1).bfloat16()
     R = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi == L.EPI_BIAS_RESIDUAL else None
     outs = {}
-    times = {128: [], 256: [], 257: [], 232: []}
+    times = {v: [] for v in VARIANTS}
     for rnd in range(6):
-        for v in (128, 256, 257, 232):                      # 257 = the 256 kernel launched persistent (one workgroup per CU)
-            L.check(lib.seedmi_set_option(b"gemm", 256 if v == 257 else v), "set_option")
-            L.check(lib.seedmi_set_option(b"gemm_persist", 1 if v in (257, 232) else 0), "set_option")
+        for v in VARIANTS:                                  # persistent launch (one workgroup per CU) for all but 128
+            L.check(lib.seedmi_set_option(b"gemm", v), "set_option")
             C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -39,13 +43,13 @@ for name, M, N, K, epi in SHAPES:
             if rnd > 0:
                 times[v].append(e0.elapsed_time(e1))
             outs[v] = C
-    same = torch.equal(outs[128], outs[256]) and torch.equal(outs[128], outs[257])
-    same32 = torch.equal(outs[128], outs[232])
-    relx = ((outs[232].float() - outs[128].float()).norm() / outs[128].float().norm()).item()
     fl = 2.0 * M * N * K
-    r = {v: round(fl / (sorted(t)[len(t) // 2] * 1e-3) / 1e12, 1) for v, t in times.items()}
-    res[name] = {"M": M, "N": N, "K": K, "TF_128": r[128], "TF_256": r[256], "TF_256_persistent": r[257], "TF_256x32": r[232], "bit_identical": same, "x32_identical": same32, "x32_rel": relx,
-                 "ms_128": round(sorted(times[128])[2], 4), "ms_256": round(sorted(times[256])[2], 4)}
+    res[name] = {"M": M, "N": N, "K": K}
+    for v in VARIANTS:
+        med = sorted(times[v])[len(times[v]) // 2]
+        res[name]["TF_%d" % v] = round(fl / (med * 1e-3) / 1e12, 1)
+        res[name]["ms_%d" % v] = round(med, 4)
+        res[name]["same_as_128_%d" % v] = torch.equal(outs[VARIANTS[0]], outs[v])
     print(name, res[name], flush=True)
 lib.seedmi_set_option(b"gemm", 0)
 lib.seedmi_set_option(b"gemm_persist", 1)

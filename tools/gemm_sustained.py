@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Sustained (DVFS-steady) GEMM rates: each shape is launched REPS times back to back with no host sync in between, for the
+hand-written kernel variants and (calibration only) the vendor library through torch.nn.functional.linear."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from seed_amd import lib as L  # noqa: E402
+
+lib = L.load()
+B = int(os.environ.get("B", "256"))
+REPS = int(os.environ.get("REPS", "80"))
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "256").split(",")]
+SHAPES = [("qkv", B * 257, 4224, 1408, L.EPI_BIAS), ("proj", B * 257, 1408, 1408, L.EPI_BIAS_RESIDUAL),
+          ("fc1", B * 257, 6144, 1408, L.EPI_BIAS_GELU), ("fc2", B * 257, 1408, 6144, L.EPI_BIAS_RESIDUAL),
+          ("square8k", 8192, 8192, 8192, L.EPI_BIAS)]
+res = {}
+for name, M, N, K, epi in SHAPES:
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    W = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+    bias = (torch.randn(N, device="cuda") * 0.1).bfloat16()
+    R = torch.randn(M, N, device="cuda").bfloat16() if epi == L.EPI_BIAS_RESIDUAL else None
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+
+    def run(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REPS):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / REPS
+        return round(ms, 4), round(2.0 * M * N * K / ms / 1e9, 1)
+
+    row = {}
+    for v in VARIANTS:
+        L.check(lib.seedmi_set_option(b"gemm", v), "opt")
+        row["own_%d" % v] = run(lambda: L.check(lib.seedmi_gemm_bf16(
+            M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(R), N if R is not None else 0, epi, L.ptr(C), N, 0, 0,
+            L.stream_ptr()), "gemm"))
+    lib.seedmi_set_option(b"gemm", 0)
+    row["vendor_linear"] = run(lambda: torch.nn.functional.linear(A, W, bias))
+    res[name] = row
+    print(name, row, flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/gemm_sustained.json", "w"), indent=1)
