@@ -56,6 +56,7 @@ int seedmi_set_option(const char* key, int value);
 #define SEEDMI_EPI_BIAS_TANH 4     /* qformer_quantizer.py:219-221                                                */
 #define SEEDMI_EPI_SWIGLU 5        /* llama_xformer.py:186 on row-interleaved gate/up weights; C is [M, N/2]        */
 #define SEEDMI_EPI_PATCH_EMBED 6   /* eva_vit.py:229 + 373-377: conv bias + pos_embed, output rows skip one cls row */
+#define SEEDMI_EPI_RELU 7          /* qformer_quantizer.py:279-285 (image_down: bias-free Linear + ReLU; bias may be NULL) */
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]);  bf16 in/out, fp32 MFMA accumulation.  K % 64 == 0.
  * residual/ldr: used by BIAS_RESIDUAL (same row as C) and PATCH_EMBED (pos_embed, row = m % row_group + row_extra;
@@ -171,6 +172,28 @@ size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int 
  * seed_llama_tokenizer.py:75-90): images [B,3,S,S] (fp32 or bf16) -> ids int64 [B, n_query] in [0, n_embed). */
 int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch, void* ids_i64,
                     const seedmi_tokenizer_taps_t* taps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- path level: de-tokenizer front half ------------------------------------------------------------------------- */
+typedef struct {
+    int n_embed, code_dim, code_pad;  /* code_pad = code_dim zero padded to a multiple of 64 (GEMM K granularity)   */
+    int dim, heads, ffn, depth;       /* blocks_image: vit.Block(768, 12 heads, mlp 4.0) x decode_depth              */
+    int n_query, down1, down2, down3, out_dim;   /* image_down widths (256, 128, 32); distill output (1024)          */
+    const void* codebook_pad;         /* quantize.embedding.weight [n_embed, code_pad] (columns >= code_dim zero)    */
+    const void *dec_w0, *dec_b0;      /* decode_task_layer.0 padded to [code_pad, code_pad], [code_pad]              */
+    const void *dec_w1, *dec_b1;      /* decode_task_layer.2 [dim, code_pad] (K zero padded), [dim]                  */
+    const void* pos_embed_image;      /* [n_query, dim]                                                              */
+    const seedmi_vit_layer_t* blocks; /* host array [depth]: blocks_image.N (qkv bias is the module's own [3*dim])    */
+    const void *down_w0, *down_w1, *down_w2;     /* image_down.{0,2,4}.weight [down1,dim] [down2,down1] [down3,down2] */
+    const void *distill_w, *distill_b;           /* distill_image_proj [out_dim, n_query*down3], [out_dim]           */
+} seedmi_detok_weights_t;
+
+size_t seedmi_detokenize_workspace_bytes(const seedmi_detok_weights_t* w, int batch);
+/* Blip2QformerQuantizer.get_codebook_entry (qformer_quantizer.py:309-338, use_qformer_image = False branch) as called by
+ * ImageTokenizer.decode (seed_llama_tokenizer.py:92-100): ids int64 [B, n_query] -> unCLIP image embeds bf16 [B, out_dim]
+ * (the conditioning handed to the diffusers pipeline, which stays outside this library).  hidden (optional) receives the
+ * blocks_image output [B*n_query, dim] for parity checks. */
+int seedmi_detokenize(const seedmi_detok_weights_t* w, const void* ids_i64, int batch, void* embeds, void* hidden,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- path level: LLaMA forward --------------------------------------------------------------------------------- */
 typedef struct {

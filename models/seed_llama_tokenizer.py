@@ -69,8 +69,25 @@ class ImageTokenizer:
             id, _ = self.model.get_codebook_indices(img)
         return id.view(img.shape[0], -1)
 
+    def decode_embeds(self, indices):
+        """The accelerated front half of ``decode``: ids -> the unCLIP conditioning ``image_embeds`` [B,1024]
+        (``self.model.get_codebook_entry``, seed_llama_tokenizer.py:93)."""
+        return self.model.get_codebook_entry(indices)
+
     def decode(self, indices, negative_indices=None, guidance_scale=10, num_inference_steps=20):
-        raise NotImplementedError("image de-tokenization (unCLIP) is outside the accelerated hot path")
+        image_embeds = self.model.get_codebook_entry(indices)
+        if negative_indices is not None:
+            assert indices.shape == negative_indices.shape, 'Negative indices must have the same shape with indices'
+            negative_image_embeds = self.model.get_codebook_entry(negative_indices)
+        else:
+            negative_image_embeds = None
+        if self.diffusion_model is None:
+            raise NotImplementedError(
+                "the StableUnCLIP pipeline (diffusers) is not part of this library: attach one as "
+                "`image_tokenizer.diffusion_model` or use decode_embeds() for the conditioning embeds")
+        return self.diffusion_model(image_embeds=image_embeds, negative_image_embeds=negative_image_embeds,
+                                    guidance_scale=guidance_scale, noise_level=0, num_inference_steps=num_inference_steps,
+                                    latents=getattr(self, "latents", None)).images
 
 
 class SeedLlamaTokenizer(LlamaTokenizer):

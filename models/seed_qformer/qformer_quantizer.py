@@ -4,14 +4,16 @@
 (``from_pretrained(pretrained_model_path, **kwargs)``, ``get_codebook_indices(image) -> (embed_ind, query_output_up)``,
 ``.to()/.half()/.eval()``, attributes ``n_embed``, ``visual_encoder``) — qformer_quantizer.py:143-375 — but holds
 no torch modules: the state dict is repacked once into the HIP engine (seed_amd/tokenizer_engine.py) and
-``get_codebook_indices`` is a single C-ABI call (seedmi_tokenize).  The de-tokenizer half
-(``get_codebook_entry`` -> unCLIP, qformer_quantizer.py:309-338) is outside this round's scope and
-raises.
+``get_codebook_indices`` is a single C-ABI call (seedmi_tokenize).  The de-tokenizer front half
+(``get_codebook_entry``, qformer_quantizer.py:309-338: ids -> unCLIP image embeds) is a single C-ABI call too
+(seedmi_detokenize) when the checkpoint carries ``blocks_image`` / ``image_down`` / ``distill_image_proj``; the diffusers
+pipeline behind it stays outside this library.
 """
 import torch
 
 from seed_amd.config import TokenizerConfig, SEED2
 from seed_amd.tokenizer_engine import TokenizerEngine
+from seed_amd.detokenizer_engine import DetokenizerEngine, has_detokenizer_weights
 
 
 class _DeviceHandle:
@@ -38,6 +40,7 @@ class Blip2QformerQuantizer:
         self._state_dict = state_dict
         self._device = torch.device(device) if device is not None else None
         self._engine = None
+        self._detok = None
 
     # -- reference constructor path (qformer_quantizer.py:340-375)
     @classmethod
@@ -64,6 +67,8 @@ class Blip2QformerQuantizer:
             dev = torch.device(device)
             if self._engine is not None and dev != self._engine.device:
                 self._engine = None
+            if self._detok is not None and dev != self._detok.device:
+                self._detok = None
             self._device = dev
         return self
 
@@ -81,5 +86,16 @@ class Blip2QformerQuantizer:
         with torch.no_grad():
             return self.engine.encode(image), None
 
+    @property
+    def detokenizer(self) -> DetokenizerEngine:
+        if self._detok is None:
+            if self._state_dict is None or not has_detokenizer_weights(self._state_dict):
+                raise RuntimeError("this checkpoint carries no de-tokenizer weights (blocks_image / image_down / "
+                                   "distill_image_proj)")
+            self._detok = DetokenizerEngine(self._state_dict, self.cfg, device=self._device)     # raises without a GPU
+        return self._detok
+
     def get_codebook_entry(self, indices):
-        raise NotImplementedError("de-tokenizer (codebook entry -> unCLIP embedding) is outside the accelerated hot path")
+        """qformer_quantizer.py:309-338 (use_qformer_image=False): ids [B,32] -> image embeds [B,1024] (half tensor)."""
+        with torch.no_grad():
+            return self.detokenizer.codebook_entry(indices)

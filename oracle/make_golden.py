@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 
 from oracle import ref_shims  # noqa: E402
 from seed_amd import config as C  # noqa: E402
-from seed_amd.weights import make_tokenizer_state_dict, make_llama_state_dict, calibrate_codebook  # noqa: E402
+from seed_amd.weights import (make_tokenizer_state_dict, make_llama_state_dict, calibrate_codebook,  # noqa: E402
+                              make_detokenizer_state_dict)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -142,6 +143,22 @@ def llama_golden(ref):
     print("llama golden tokens", outs["tokens_fp32"].tolist(), outs["tokens_bf16"].tolist())
 
 
+def detok_golden(name, cfg, batch, seed_w, seed_ids, ref):
+    """Blip2QformerQuantizer.get_codebook_entry on the reference's own sub-modules (vit.Block, VectorQuantizer2, ...):
+    ids -> image embeds, fp32 and natively-bf16 runs."""
+    sd = make_detokenizer_state_dict(cfg, seed=seed_w)
+    mods = ref_shims.build_reference_detokenizer_modules(ref, cfg)
+    mods.load_state_dict(sd, strict=True)          # also proves the key names / shapes match the reference modules
+    gen = torch.Generator().manual_seed(seed_ids)
+    ids = torch.randint(0, cfg.n_embed, (batch, cfg.n_query), generator=gen)
+    out32, hid32 = ref_shims.reference_get_codebook_entry(mods, ids)
+    out16, hid16 = ref_shims.reference_get_codebook_entry(mods.bfloat16(), ids)
+    np.savez_compressed(os.path.join(GOLDEN, f"detok_{name}.npz"), seed_w=seed_w, ids=ids.numpy(),
+                        embeds_fp32=out32.numpy(), embeds_bf16=out16.float().numpy(),
+                        hidden_fp32_slice=hid32[:, :4, :64].numpy(), hidden_bf16_slice=hid16[:, :4, :64].float().numpy())
+    print("detok", name, "embeds[0,:4]", out32[0, :4].tolist(), "bf16 rel", ((out16.float() - out32).norm() / out32.norm()).item())
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -150,6 +167,8 @@ def main():
     tokenizer_golden("tiny", C.TINY, 3, 0, 1234, ref)
     tokenizer_golden("mid", C.MID, 2, 1, 4321, ref)
     llama_golden(ref)
+    detok_golden("tiny", C.TINY, 3, 11, 5, ref)
+    detok_golden("full", C.SEED2, 2, 12, 6, ref)
 
 
 if __name__ == "__main__":

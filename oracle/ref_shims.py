@@ -61,11 +61,34 @@ def _install_shims():
         layers.trunc_normal_ = nn.init.trunc_normal_
         hub.download_cached_file = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("offline"))
         hub.get_cache_dir = lambda *a, **k: "/tmp"
+        # models/seed_qformer/vit.py:17-20 (the de-tokenizer's Block lives there) imports a few more timm names; only
+        # DropPath is ever instantiated on our path, and only with drop_prob == 0 (vit.py:133 picks nn.Identity then)
+        class DropPath(nn.Module):
+            def __init__(self, drop_prob=0.0):
+                super().__init__()
+                assert drop_prob == 0.0
+            def forward(self, x):
+                return x
+
+        layers.DropPath = DropPath
+        vt = types.ModuleType("timm.models.vision_transformer")
+        vt._cfg = lambda **kw: dict(kw)
+        vt.PatchEmbed = type("PatchEmbed", (nn.Module,), {})
+        reg = types.ModuleType("timm.models.registry")
+        reg.register_model = lambda fn: fn
+        helpers = types.ModuleType("timm.models.helpers")
+        helpers.named_apply = lambda *a, **k: None
+        helpers.adapt_input_conv = lambda *a, **k: None
         timm.models = timm_models
         timm_models.layers = layers
         timm_models.hub = hub
+        timm_models.vision_transformer = vt
+        timm_models.registry = reg
+        timm_models.helpers = helpers
         sys.modules.update({"timm": timm, "timm.models": timm_models,
-                            "timm.models.layers": layers, "timm.models.hub": hub})
+                            "timm.models.layers": layers, "timm.models.hub": hub,
+                            "timm.models.vision_transformer": vt, "timm.models.registry": reg,
+                            "timm.models.helpers": helpers})
 
     for name in ("apply_chunking_to_forward", "prune_linear_layer"):
         if not hasattr(mu, name):
@@ -204,3 +227,45 @@ def reference_get_codebook_indices(mods, query_tokens, image):
         quant, loss_embed, embed_ind = mods.quantize(query_output_down)
         embed_ind = embed_ind.reshape(quant.shape[0], -1)
     return embed_ind, dict(image_embeds=image_embeds, qformer_out=query_output.last_hidden_state, z=query_output_down)
+
+
+def build_reference_detokenizer_modules(ref, cfg):
+    """The reference sub-modules get_codebook_entry touches, instantiated as Blip2QformerQuantizer.__init__ does
+    (models/seed_qformer/qformer_quantizer.py:217, 225-229, 249-262, 279-286) with the network constructors bypassed."""
+    from functools import partial
+    vit_mod = sys.modules[f"{_PKG}.vit"]
+    Q = cfg.qf_dim
+    quantize = ref.quantizer.VectorQuantizer2(cfg.n_embed, cfg.code_dim, beta=0.25, remap=None, sane_index_shape=False)
+    decode_task_layer = nn.Sequential(nn.Linear(cfg.code_dim, cfg.code_dim), nn.Tanh(), nn.Linear(cfg.code_dim, Q))
+    blocks_image = nn.ModuleList([
+        vit_mod.Block(dim=Q, num_heads=cfg.dec_heads, mlp_ratio=cfg.dec_mlp_ratio, qkv_bias=True, qk_scale=None, drop=0.0,
+                      attn_drop=0.0, drop_path=0.0, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+        for _ in range(cfg.decode_depth)])
+    image_down = nn.Sequential(nn.Linear(Q, cfg.down1, bias=False), nn.ReLU(), nn.Linear(cfg.down1, cfg.down2, bias=False),
+                               nn.ReLU(), nn.Linear(cfg.down2, cfg.down3, bias=False))
+    distill_image_proj = nn.Linear(cfg.n_query * cfg.down3, cfg.image_features_dim)
+    holder = nn.Module()
+    holder.quantize = quantize
+    holder.decode_task_layer = decode_task_layer
+    holder.pos_embed_image = nn.Parameter(torch.zeros(1, cfg.n_query, Q))
+    holder.blocks_image = blocks_image
+    holder.image_down = image_down
+    holder.distill_image_proj = distill_image_proj
+    return holder.eval()
+
+
+def reference_get_codebook_entry(mods, indices):
+    """Line-for-line re-assembly of Blip2QformerQuantizer.get_codebook_entry for use_qformer_image=False
+    (models/seed_qformer/qformer_quantizer.py:309-320, 332-338) on the reference sub-modules."""
+    with torch.no_grad():
+        quant_embedding = mods.quantize.get_codebook_entry(indices)
+        query_output_up = mods.decode_task_layer(quant_embedding)
+        pos_embed_image = mods.pos_embed_image.repeat(query_output_up.shape[0], 1, 1)
+        query_output_up_pos_image = query_output_up + pos_embed_image
+        for blk in mods.blocks_image:
+            query_output_up_pos_image = blk(query_output_up_pos_image)
+        query_output_up = query_output_up_pos_image
+        reverse_output = mods.image_down(query_output_up)
+        reverse_output = reverse_output.reshape(reverse_output.shape[0], -1)
+        reverse_output_proj = mods.distill_image_proj(reverse_output)
+    return reverse_output_proj, query_output_up

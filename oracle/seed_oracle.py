@@ -272,6 +272,54 @@ def get_codebook_indices(sd: Dict[str, torch.Tensor], image: torch.Tensor, cfg, 
     return ids.reshape(image.shape[0], -1)
 
 
+# ----------------------------------------------------------------------------- de-tokenizer front half
+
+
+def detok_block(sd, i, x, cfg, prec: Prec):
+    """vit.Block.forward (models/seed_qformer/vit.py:147-150) with Attention.forward (:85-105) and Mlp (:41-47); the module
+    is .half()'ed and runs outside autocast (seed_llama_tokenizer.py:62-63, 92-93), so LayerNorm / softmax / GELU outputs
+    are half tensors too."""
+    p = f"blocks_image.{i}."
+    B, N, C = x.shape
+    H = cfg.dec_heads
+    hd = C // H
+    h = prec.r(layer_norm(x, _w(sd, p + "norm1.weight", prec), _w(sd, p + "norm1.bias", prec), 1e-6))
+    qkv = linear(h, _w(sd, p + "attn.qkv.weight", prec), _w(sd, p + "attn.qkv.bias", prec), prec)      # :87
+    qkv = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = prec.r(prec.r(q @ k.transpose(-2, -1)) * (hd ** -0.5))                                         # :94
+    attn = prec.r(attn.softmax(dim=-1))                                                                  # :95
+    a = prec.r(attn @ v).transpose(1, 2).reshape(B, N, C)                                                # :102
+    a = linear(a, _w(sd, p + "attn.proj.weight", prec), _w(sd, p + "attn.proj.bias", prec), prec)      # :103
+    x = prec.r(x + a)                                                                                    # :148
+    h = prec.r(layer_norm(x, _w(sd, p + "norm2.weight", prec), _w(sd, p + "norm2.bias", prec), 1e-6))
+    h = linear(h, _w(sd, p + "mlp.fc1.weight", prec), _w(sd, p + "mlp.fc1.bias", prec), prec)          # :42
+    h = prec.r(gelu_erf(h))                                                                              # :43
+    h = linear(h, _w(sd, p + "mlp.fc2.weight", prec), _w(sd, p + "mlp.fc2.bias", prec), prec)          # :45
+    return prec.r(x + h)                                                                                 # :149
+
+
+def get_codebook_entry(sd: Dict[str, torch.Tensor], ids: torch.Tensor, cfg, mode: str = "fp32", taps: Optional[dict] = None):
+    """Blip2QformerQuantizer.get_codebook_entry, use_qformer_image=False (qformer_quantizer.py:309-338):
+    ids int64 [B, n_query] -> image embeds [B, image_features_dim] (fp32 tensor holding half-representable values in
+    bf16 mode)."""
+    prec = Prec(mode)
+    z_q = _w(sd, "quantize.embedding.weight", prec)[ids]                                                 # :310 / :133
+    h = linear(z_q, _w(sd, "decode_task_layer.0.weight", prec), _w(sd, "decode_task_layer.0.bias", prec), prec)
+    h = prec.r(torch.tanh(h))
+    x = linear(h, _w(sd, "decode_task_layer.2.weight", prec), _w(sd, "decode_task_layer.2.bias", prec), prec)   # :314
+    x = prec.r(x + _w(sd, "pos_embed_image", prec))                                                      # :316-317
+    for i in range(cfg.decode_depth):                                                                    # :318-319
+        x = detok_block(sd, i, x, cfg, prec)
+    if taps is not None:
+        taps["hidden"] = x.clone()
+    d = prec.r(torch.relu(linear(x, _w(sd, "image_down.0.weight", prec), None, prec)))                   # :333
+    d = prec.r(torch.relu(linear(d, _w(sd, "image_down.2.weight", prec), None, prec)))
+    d = linear(d, _w(sd, "image_down.4.weight", prec), None, prec)
+    d = d.reshape(d.shape[0], -1)                                                                        # :334
+    return linear(d, _w(sd, "distill_image_proj.weight", prec), _w(sd, "distill_image_proj.bias", prec), prec)   # :335
+
+
 # ----------------------------------------------------------------------------- LLaMA
 
 

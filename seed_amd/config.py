@@ -28,6 +28,18 @@ class TokenizerConfig:
     n_query: int = 32
     n_embed: int = 8192
     code_dim: int = 32
+    # de-tokenizer front half (qformer_quantizer.py:176-181, 249-286): blocks_image + image_down + distill_image_proj
+    decode_depth: int = 4
+    dec_heads: int = 12
+    dec_mlp_ratio: float = 4.0
+    down1: int = 256
+    down2: int = 128
+    down3: int = 32
+    image_features_dim: int = 1024
+
+    @property
+    def dec_ffn(self) -> int:  # vit.py:135  int(dim * mlp_ratio)
+        return int(self.qf_dim * self.dec_mlp_ratio)
 
     @property
     def vit_ffn(self) -> int:  # eva_vit.py:190  int(dim * mlp_ratio)
@@ -79,10 +91,12 @@ class TokenizerConfig:
 SEED2 = TokenizerConfig()
 # reduced shapes for CPU-speed parity tests (same structure: odd head dim 88-like handled by 'mid')
 TINY = TokenizerConfig(img_size=56, patch=14, vit_dim=128, vit_depth=2, vit_heads=2, vit_mlp_ratio=4.0,
-                       qf_dim=128, qf_layers=2, qf_heads=2, qf_ffn=256, n_query=32, n_embed=512, code_dim=32)
+                       qf_dim=128, qf_layers=2, qf_heads=2, qf_ffn=256, n_query=32, n_embed=512, code_dim=32,
+                       decode_depth=2, dec_heads=2, down1=128, down2=64, down3=32, image_features_dim=256)
 # keeps the MFMA-hostile dims of the real model (hd = 88, 257 tokens, 64-wide Q-Former heads) at small depth
 MID = TokenizerConfig(img_size=224, patch=14, vit_dim=704, vit_depth=2, vit_heads=8, vit_mlp_ratio=4.0,
-                      qf_dim=256, qf_layers=2, qf_heads=4, qf_ffn=512, n_query=32, n_embed=8192, code_dim=32)
+                      qf_dim=256, qf_layers=2, qf_heads=4, qf_ffn=512, n_query=32, n_embed=8192, code_dim=32,
+                      decode_depth=2, dec_heads=4)
 
 
 @dataclass(frozen=True)

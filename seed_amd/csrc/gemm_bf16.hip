@@ -108,6 +108,9 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
         } else if (EPI == EPI_BIAS_TANH) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = tanhf(rbf(v[i]));
+        } else if (EPI == EPI_RELU) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(rbf(v[i]), 0.f);
         } else if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_PATCH_EMBED) {
             int res_row = m;
             if (EPI == EPI_PATCH_EMBED) {
@@ -1051,6 +1054,7 @@ extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, con
         case EPI_BIAS_TANH: return launch_gemm<EPI_BIAS_TANH>(p, s);
         case EPI_SWIGLU: return launch_gemm<EPI_SWIGLU>(p, s);
         case EPI_PATCH_EMBED: return launch_gemm<EPI_PATCH_EMBED>(p, s);
+        case EPI_RELU: return launch_gemm<EPI_RELU>(p, s);
         default:
             seedmi_set_error("seedmi_gemm_bf16: unknown epilogue %d", epilogue);
             return SEEDMI_E_SHAPE;

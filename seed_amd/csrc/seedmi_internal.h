@@ -11,6 +11,7 @@ enum {
     EPI_BIAS_TANH = 4,      // tanh(half(. + bias))         (qformer_quantizer.py:219-221)
     EPI_SWIGLU = 5,         // silu(gate) * up on interleaved rows (llama_xformer.py:186)
     EPI_PATCH_EMBED = 6,    // conv bias + pos_embed, rows shifted past each image's cls slot (eva_vit.py:229,373-377)
+    EPI_RELU = 7,           // relu(half(. [+ bias]))       (image_down, qformer_quantizer.py:279-285)
 };
 
 // seedmi_set_option("tokenize_streams", 1|2): sub-batch overlap inside seedmi_tokenize (tokenizer.hip)

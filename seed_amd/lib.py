@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libseedmi.so")
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_BIAS_TANH, EPI_SWIGLU, EPI_PATCH_EMBED = range(7)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_BIAS_TANH, EPI_SWIGLU, EPI_PATCH_EMBED, EPI_RELU = range(8)
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -34,6 +34,14 @@ class TokenizerWeights(C.Structure):
                  ("vit", C.POINTER(VitLayer)), ("ln_vision_w", _vp), ("ln_vision_b", _vp), ("query_ln", _vp),
                  ("qf", C.POINTER(QfLayer)), ("head_w0", _vp), ("head_b0", _vp), ("head_w1", _vp), ("head_b1", _vp),
                  ("codebook", _vp), ("code_sqnorm", _vp)])
+
+
+class DetokWeights(C.Structure):
+    _fields_ = ([(n, _i) for n in ("n_embed", "code_dim", "code_pad", "dim", "heads", "ffn", "depth", "n_query", "down1", "down2",
+                                   "down3", "out_dim")] +
+                [(n, _vp) for n in ("codebook_pad", "dec_w0", "dec_b0", "dec_w1", "dec_b1", "pos_embed_image")] +
+                [("blocks", C.POINTER(VitLayer))] +
+                [(n, _vp) for n in ("down_w0", "down_w1", "down_w2", "distill_w", "distill_b")])
 
 
 class TokenizerTaps(C.Structure):
@@ -78,6 +86,8 @@ SIGNATURES = {
     "seedmi_tokenize_workspace_bytes": (C.c_size_t, [C.POINTER(TokenizerWeights), _i]),
     "seedmi_tokenize": (_i, [C.POINTER(TokenizerWeights), _vp, _i, _i, _vp, C.POINTER(TokenizerTaps), _vp,
                              C.c_size_t, _vp]),
+    "seedmi_detokenize_workspace_bytes": (C.c_size_t, [C.POINTER(DetokWeights), _i]),
+    "seedmi_detokenize": (_i, [C.POINTER(DetokWeights), _vp, _i, _vp, _vp, _vp, C.c_size_t, _vp]),
     "seedmi_llama_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaWeights), _i, _i]),
     "seedmi_llama_forward": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.c_size_t, _vp]),
     "seedmi_llama_forward_ex": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, C.c_size_t, _vp]),

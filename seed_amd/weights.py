@@ -114,6 +114,51 @@ def make_tokenizer_state_dict(cfg: TokenizerConfig, seed: int = 0, device="cpu",
     return sd
 
 
+def make_detokenizer_state_dict(cfg: TokenizerConfig, seed: int = 11, device="cpu", dtype=torch.float32,
+                                jitter: float = 0.02) -> Dict[str, torch.Tensor]:
+    """State dict of Blip2QformerQuantizer restricted to get_codebook_entry (qformer_quantizer.py:309-338,
+    use_qformer_image=False): ``quantize.embedding``, ``decode_task_layer``, ``pos_embed_image``, ``blocks_image``,
+    ``image_down``, ``distill_image_proj``.  The reference draws these with the default ``nn.Linear`` init
+    (U(+-1/sqrt(fan_in))), ``pos_embed_image`` zeros and LayerNorm 1/0 (:225-286, vit.py:123-141); ``jitter`` moves
+    the zero / one parameters off their init so the affine and positional terms are exercised.  The codebook rows are
+    N(0, 1/sqrt(code_dim)) so that tanh / GELU see O(1) inputs (the init-time U(+-1/n_embed) rows would make the whole
+    stack a constant)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    sd = {}
+    Q, cd, F = cfg.qf_dim, cfg.code_dim, cfg.dec_ffn
+
+    def lin(name, n_out, n_in, bias=True):
+        b = 1.0 / math.sqrt(n_in)
+        sd[name + ".weight"] = _uniform(gen, (n_out, n_in), b, device)
+        if bias:
+            sd[name + ".bias"] = _uniform(gen, (n_out,), b, device)
+
+    def ln(prefix, n):
+        sd[prefix + ".weight"] = torch.ones(n, device=device) + _normal(gen, (n,), jitter, device)
+        sd[prefix + ".bias"] = _normal(gen, (n,), jitter, device)
+
+    sd["quantize.embedding.weight"] = _normal(gen, (cfg.n_embed, cd), 1.0 / math.sqrt(cd), device)
+    lin("decode_task_layer.0", cd, cd)
+    lin("decode_task_layer.2", Q, cd)
+    sd["pos_embed_image"] = _normal(gen, (1, cfg.n_query, Q), jitter, device)
+    for i in range(cfg.decode_depth):
+        p = f"blocks_image.{i}."
+        ln(p + "norm1", Q)
+        lin(p + "attn.qkv", 3 * Q, Q)
+        lin(p + "attn.proj", Q, Q)
+        ln(p + "norm2", Q)
+        lin(p + "mlp.fc1", F, Q)
+        lin(p + "mlp.fc2", Q, F)
+    lin("image_down.0", cfg.down1, Q, bias=False)
+    lin("image_down.2", cfg.down2, cfg.down1, bias=False)
+    lin("image_down.4", cfg.down3, cfg.down2, bias=False)
+    lin("distill_image_proj", cfg.image_features_dim, cfg.n_query * cfg.down3)
+    if dtype != torch.float32:
+        sd = {k: v.to(dtype) for k, v in sd.items()}
+    return sd
+
+
 def calibrate_codebook(z: torch.Tensor, n_embed: int, seed: int = 7) -> torch.Tensor:
     """Synthetic codebook at the scale of a calibration run's ``z``: rows ~ mean(z) + N(0, std(z)).
 
