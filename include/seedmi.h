@@ -173,6 +173,21 @@ size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int 
 int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch, void* ids_i64,
                     const seedmi_tokenizer_taps_t* taps, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the step before the path: image pre-processing -------------------------------------------------------------- */
+#define SEEDMI_RESIZE_BILINEAR 2   /* PIL.Image.BILINEAR: transforms.Resize default, models/transforms.py:13,16      */
+#define SEEDMI_RESIZE_BICUBIC 3    /* PIL.Image.BICUBIC: interpolation=3, models/seed_llama_tokenizer.py:51           */
+size_t seedmi_preprocess_workspace_bytes(int in_h, int in_w, int resize_h, int resize_w, int filter);
+/* transforms.Resize -> [CenterCrop] -> ToTensor -> Normalize on one uint8 RGB image (models/seed_llama_tokenizer.py:50-56,
+ * models/transforms.py:8-21).  rgb_hwc: device uint8 [in_h][row_stride bytes] with 3-byte pixels; the image is resized to
+ * resize_h x resize_w with Pillow's antialiased 8-bit resampler (bit-exact: same fixed-point coefficients and the uint8
+ * rounding after each of the two passes), the window [crop_top, +out_h) x [crop_left, +out_w) of the result is taken,
+ * divided by 255 and normalised with mean3/std3 (host pointers) in fp32, and written as [3][out_h][out_w] fp32 or bf16.
+ * out_u8_hwc (optional) receives the resized+cropped uint8 image [out_h][out_w][3] for parity checks. */
+int seedmi_preprocess_image_u8(const void* rgb_hwc, int in_h, int in_w, int row_stride, int resize_h, int resize_w, int filter,
+                               int crop_top, int crop_left, int out_h, int out_w, const float* mean3, const float* std3,
+                               void* out_chw, int out_is_fp32, void* out_u8_hwc, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* ---- path level: de-tokenizer front half ------------------------------------------------------------------------- */
 typedef struct {
     int n_embed, code_dim, code_pad;  /* code_pad = code_dim zero padded to a multiple of 64 (GEMM K granularity)   */

@@ -11,7 +11,8 @@ no data collective is needed (ranks only rendezvous); launch with
         -m seed_amd.tools.extract_image_ids --images /data/imgs --save_dir /data/ids --batch_size 1024
 
 Inputs: a directory of image files (optionally ``<name>.txt`` captions next to them), or ``synthetic:N`` for N random
-224x224 tensors.  JPEG decode + CLIP resize/normalise run on the host (models/transforms.py) — the step before the hot path.
+224x224 tensors.  JPEG decode runs on the host; the CLIP resize/normalise (models/transforms.py) runs on the host too or, with
+--gpu-preprocess, in seedmi_preprocess_image_u8 (bit-exact with the PIL path) — the step before the hot path.
 """
 import argparse
 import io
@@ -78,6 +79,7 @@ def run(encode_fn: Callable[[torch.Tensor], torch.Tensor], items: List, load_fn:
     for s in range(b, e, batch_size):
         chunk = items[s:min(s + batch_size, e)]
         tensors, texts, metas = zip(*(load_fn(it) for it in chunk))
+        # host-preprocessed samples are CPU tensors; with --gpu-preprocess each is already a [3,224,224] device tensor
         batch = torch.stack(tensors).to(device, non_blocking=True)
         ids = encode_fn(batch)                                    # [B, 32] int64 on device
         ids = ids.view(len(chunk), -1).cpu().tolist()             # the reference's `.view(-1).cpu().tolist()` per sample
@@ -95,6 +97,9 @@ def main():
     ap.add_argument("--save_dir", required=True)
     ap.add_argument("--batch_size", type=int, default=1024)
     ap.add_argument("--weights", default=None, help="seed_quantizer.pt (default: seeded synthetic weights)")
+    ap.add_argument("--gpu-preprocess", action="store_true",
+                    help="resize/normalise on the device (seedmi_preprocess_image_u8, bit-exact with the PIL path); "
+                         "only the JPEG decode stays on the host")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -118,6 +123,9 @@ def main():
         from PIL import Image
         from models.transforms import get_transform
         tf = get_transform(type="clip", keep_ratio=False, image_size=224)
+        if args.gpu_preprocess:
+            from seed_amd.preprocess import DevicePreprocessor, BILINEAR
+            tf = DevicePreprocessor(224, interpolation=BILINEAR, keep_ratio=False, device=f"cuda:{local}")   # same ops as tf
         items = list_images(args.images)
 
         def load(path):
