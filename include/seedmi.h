@@ -173,6 +173,11 @@ size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int 
 int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch, void* ids_i64,
                     const seedmi_tokenizer_taps_t* taps, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- calibration (not on the product path) ---------------------------------------------------------------------------- */
+/* Streams `bytes` of device memory with 16-byte non-temporal loads from 256*blocks_per_cu workgroups (the decode GEMMs' access
+ * pattern) and discards them: the HBM read rate this box actually delivers, for the "vs measured" roofline. */
+int seedmi_bench_stream_read(const void* p, size_t bytes, int blocks_per_cu, void* scratch4, void* stream);
+
 /* ---- the step before the path: image pre-processing -------------------------------------------------------------- */
 #define SEEDMI_RESIZE_BILINEAR 2   /* PIL.Image.BILINEAR: transforms.Resize default, models/transforms.py:13,16      */
 #define SEEDMI_RESIZE_BICUBIC 3    /* PIL.Image.BICUBIC: interpolation=3, models/seed_llama_tokenizer.py:51           */

@@ -26,6 +26,44 @@ struct SkinnyParams {
     int a_packed, c_packed;      // activations / SWIGLU output in the fragment-major layout (see norm_misc.hip PACK)
 };
 
+// wave 0's epilogue: lane (li, g) owns rows m = 16 t + li and the four columns n0 + 16 r + 4 g .. +3
+template <int MT, int EPI, int R>
+SEEDMI_DEVINL void skinny_epilogue(const SkinnyParams& p, f32x4 (&acc)[R][MT], int n0, int li, int g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = 16 * t + li;
+        const int nb_ = n0 + 16 * r + 4 * g;
+        if (m >= p.M || nb_ >= p.N) continue;
+        float v[4] = {acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]};
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            const bf16_t* rp = p.R + (size_t)m * p.ldr + nb_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) v[e] = rbf(v[e]) + bf2f(rp[e]);
+        }
+        if (EPI == EPI_SWIGLU) {
+            const int kc = nb_ >> 1;                                     // output column of the first (gate, up) pair
+            bf16_t* cp = p.c_packed
+                ? p.C + ((size_t)((m >> 4) * (p.N >> 6) + (kc >> 5)) * 64 + ((kc >> 3) & 3) * 16 + (m & 15)) * 8 + (kc & 7)
+                : p.C + (size_t)m * p.ldc + kc;
+            if (nb_ + 1 < p.N) cp[0] = f2bf(rbf(silu(rbf(v[0]))) * rbf(v[1]));
+            if (nb_ + 3 < p.N) cp[1] = f2bf(rbf(silu(rbf(v[2]))) * rbf(v[3]));
+        } else {
+            bf16_t* cp = p.C + (size_t)m * p.ldc + nb_;
+            if (nb_ + 4 <= p.N && (p.ldc % 4) == 0) {
+                uint2 w;
+                w.x = pack2bf(v[0], v[1]);
+                w.y = pack2bf(v[2], v[3]);
+                *(uint2*)cp = w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) cp[e] = f2bf(v[e]);
+            }
+        }
+    }
+}
+
 // NW waves split K; every wave keeps two register sets of U k-steps in flight (the next batch is requested before
 // the current one is consumed), i.e. up to 2*U*(1+MT) 16-byte loads per lane outstanding — what a one-workgroup-per-CU
 // launch (N/16 = 256 workgroups for the 4096-row projections) needs to cover HBM latency.
@@ -109,40 +147,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int w = 0; w < NW - 1; ++w)
+            for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[r][t][e] += red[w][r][t][lane][e];
-        const int m = 16 * t + li;
-        const int nb_ = n0 + 16 * r + 4 * g;
-        if (m >= p.M || nb_ >= p.N) continue;
-        float v[4] = {acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]};
-        if (EPI == EPI_BIAS_RESIDUAL) {
-            const bf16_t* rp = p.R + (size_t)m * p.ldr + nb_;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) v[e] = rbf(v[e]) + bf2f(rp[e]);
-        }
-        if (EPI == EPI_SWIGLU) {
-            const int kc = nb_ >> 1;                                     // output column of the first (gate, up) pair
-            bf16_t* cp = p.c_packed
-                ? p.C + ((size_t)((m >> 4) * (p.N >> 6) + (kc >> 5)) * 64 + ((kc >> 3) & 3) * 16 + (m & 15)) * 8 + (kc & 7)
-                : p.C + (size_t)m * p.ldc + kc;
-            if (nb_ + 1 < p.N) cp[0] = f2bf(rbf(silu(rbf(v[0]))) * rbf(v[1]));
-            if (nb_ + 3 < p.N) cp[1] = f2bf(rbf(silu(rbf(v[2]))) * rbf(v[3]));
-        } else {
-            bf16_t* cp = p.C + (size_t)m * p.ldc + nb_;
-            if (nb_ + 4 <= p.N && (p.ldc % 4) == 0) {
-                uint2 w;
-                w.x = pack2bf(v[0], v[1]);
-                w.y = pack2bf(v[2], v[3]);
-                *(uint2*)cp = w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) cp[e] = f2bf(v[e]);
-            }
-        }
-    }
+                for (int e = 0; e < 4; ++e) acc[r][t][e] += red[w][r][t][lane][e];
+    skinny_epilogue<MT, EPI, R>(p, acc, n0, li, g);
 }
 
 int g_skinny_nt = 1, g_skinny_nw = 0;

@@ -86,6 +86,7 @@ SIGNATURES = {
     "seedmi_tokenize_workspace_bytes": (C.c_size_t, [C.POINTER(TokenizerWeights), _i]),
     "seedmi_tokenize": (_i, [C.POINTER(TokenizerWeights), _vp, _i, _i, _vp, C.POINTER(TokenizerTaps), _vp,
                              C.c_size_t, _vp]),
+    "seedmi_bench_stream_read": (_i, [_vp, C.c_size_t, _i, _vp, _vp]),
     "seedmi_preprocess_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "seedmi_preprocess_image_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         _vp, _i, _vp, _vp, C.c_size_t, _vp]),
