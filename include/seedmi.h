@@ -106,6 +106,12 @@ int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, c
                           int past_len, const void* past_len_dev, void* stream);
 /* *counter += delta on the stream (the decode graph advances its device-resident cache length with it). */
 int seedmi_add_i32(void* counter_dev, int delta, void* stream);
+/* Decode step (T == 1) of LlamaAttention.forward with apply_rotary_pos_emb, the cache append and the attention in one launch
+ * (llama_xformer.py:147-168, 228-256): qkv [B, 3*H*hd] (q|k|v) un-rotated; the new key/value row is written to the caches at
+ * past_len (or *past_len_dev) and attended to together with the cached rows.  pos_ids_i64 [B] may be NULL (position = past). */
+int seedmi_llama_decode_attention_bf16(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t, const void* sin_t,
+                                       void* k_cache, void* v_cache, void* out, int ldo, int B, int H, int hd, int tmax,
+                                       int past_len, float scale, int out_packed, const void* past_len_dev, void* stream);
 /* xformers.ops.memory_efficient_attention semantics (llama_xformer.py:244-256), head_dim 128:
  * q [B*T, H*hd]; caches [B][H][tmax][hd] holding kv_len = past_len + T keys; causal (top-left aligned on the
  * last T positions) when T > 1. */
@@ -172,6 +178,18 @@ size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int 
  * seed_llama_tokenizer.py:75-90): images [B,3,S,S] (fp32 or bf16) -> ids int64 [B, n_query] in [0, n_embed). */
 int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch, void* ids_i64,
                     const seedmi_tokenizer_taps_t* taps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the step after the path: next-token selection ------------------------------------------------------------------- */
+/* Greedy argmax (uniforms_f32 == NULL or top_p == 0; first index on ties) or temperature + top-p sampling of one token per row
+ * of logits bf16 [batch, ldl] (columns >= vocab ignored), the logits-processor + multinomial part of GenerationMixin.sample for
+ * the scripts' generation_config (scripts/seed_llama_inference_8B.py:81-87): weights exp((l - max) / temperature); a token is
+ * kept iff the weight mass ranked before it (descending weight, ties by ascending id) is < top_p * total; the draw is the
+ * inverse CDF over the kept tokens in that order at uniforms_f32[step * batch + row] (in [0,1)), step = *step_dev (device int32,
+ * may be NULL = 0) + step_offset.  Writes tok_out_i64[row] and, when history_i64 != NULL, history_i64[row * history_ld + step].
+ * No host sync: a captured decode graph replays it with the step read from device memory. */
+int seedmi_sample_token_bf16(const void* logits, int ldl, int batch, int vocab, float temperature, float top_p,
+                             const void* uniforms_f32, const void* step_dev, int step_offset, void* tok_out_i64,
+                             void* history_i64, int history_ld, void* stream);
 
 /* ---- calibration (not on the product path) ---------------------------------------------------------------------------- */
 /* Streams `bytes` of device memory with 16-byte non-temporal loads from 256*blocks_per_cu workgroups (the decode GEMMs' access

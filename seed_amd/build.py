@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libseedmi.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["capi.hip", "gemm_bf16.hip", "attn_fullrow.hip", "attn_vit.hip", "norm_misc.hip", "vq_argmin.hip", "tokenizer.hip", "detokenizer.hip", "preprocess.hip", "llama.hip"]
+SOURCES = ["capi.hip", "gemm_bf16.hip", "attn_fullrow.hip", "attn_vit.hip", "norm_misc.hip", "vq_argmin.hip", "tokenizer.hip", "detokenizer.hip", "preprocess.hip", "sample.hip", "llama.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
 int g_skinny_nt = 1, g_skinny_nw = 0;
 
 int g_skinny_r = 0;
+int g_decode_fused = 1;              // seedmi_set_option("decode_fused", 0|1): RoPE + KV append folded into decode attention
 
 template <int EPI, int NW, bool NT, bool PACKED, int R>
 int launch_skinny_r(const SkinnyParams& p, hipStream_t s) {
@@ -265,6 +266,116 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     for (int j = ks; j < kv_len; j += 16) {
         const float pj = rbf(sc[j] * inv);
         const uint4 u = *(const uint4*)(vb + (size_t)j * DEC_HD + 8 * c);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] += pj * lo_bf(w[i]); o[2 * i + 1] += pj * hi_bf(w[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[ks * DEC_HD + 8 * c + i] = o[i];
+    __syncthreads();
+    if (tid < DEC_HD) {
+        float a = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) a += part[s2 * DEC_HD + tid];
+        const int kcol = h * DEC_HD + tid;
+        const size_t off = out_packed
+            ? ((size_t)((b >> 4) * ((H * DEC_HD) >> 5) + (kcol >> 5)) * 64 + ((kcol >> 3) & 3) * 16 + (b & 15)) * 8 + (kcol & 7)
+            : (size_t)b * ldo + kcol;
+        out[off] = f2bf(a);
+    }
+}
+
+// Decode step with RoPE and the KV-cache append folded in (T == 1): the workgroup of (b, h) rotates its own q and the new
+// key (same half-precision expression and rounding points as rope_kv_append_kernel, llama_xformer.py:147-168), stores the new
+// key / value row in the cache for the following steps, and attends over the cached rows plus the new one taken from
+// registers.  One launch per layer instead of two and no q round trip; results are bit-identical to the two-kernel form.
+__global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
+                                                               const long long* __restrict__ pos_ids,
+                                                               const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t,
+                                                               bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                               bf16_t* __restrict__ out, int ldo, int H, int tmax, int past_arg,
+                                                               float scale, int out_packed, int lds_len,
+                                                               const int* __restrict__ past_dev) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int past = past_dev ? *past_dev : past_arg;
+    const int kv_len = past + 1;
+    float* sc = dsm;
+    float* part = dsm + lds_len;
+    __shared__ float wred[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int c = tid & 15;                         // 16-B chunk of the head dim: elements 8c .. 8c+7
+    const int ks = tid >> 4;                        // key slot 0..15
+    bf16_t* kb = kc + ((size_t)b * H + h) * tmax * DEC_HD;
+    bf16_t* vb = vc + ((size_t)b * H + h) * tmax * DEC_HD;
+    const long long pos = pos_ids ? pos_ids[b] : (long long)past;
+    // rotate q and the new key: element i pairs with i +- 64, i.e. chunk c with chunk c ^ 8
+    float qv[8], kn[8];
+    uint4 vnew;
+    {
+        const bf16_t* row = qkv + (size_t)b * ldqkv + h * DEC_HD;
+        const bool lo = c < 8;                      // first half: x*cos + (-partner)*sin ; second half: x*cos + partner*sin
+        const uint4 uc = *(const uint4*)(cos_t + pos * DEC_HD + 8 * c);
+        const uint4 us = *(const uint4*)(sin_t + pos * DEC_HD + 8 * c);
+        const uint32_t cw[4] = {uc.x, uc.y, uc.z, uc.w}, sw[4] = {us.x, us.y, us.z, us.w};
+        auto rot = [&](const bf16_t* x, float (&dst)[8]) {
+            const uint4 a = *(const uint4*)(x + 8 * c), p2 = *(const uint4*)(x + 8 * (c ^ 8));
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, pw[4] = {p2.x, p2.y, p2.z, p2.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x0 = lo_bf(aw[i]), x1 = hi_bf(aw[i]);
+                const float y0 = lo ? -lo_bf(pw[i]) : lo_bf(pw[i]), y1 = lo ? -hi_bf(pw[i]) : hi_bf(pw[i]);
+                dst[2 * i] = rbf(rbf(x0 * lo_bf(cw[i])) + rbf(y0 * lo_bf(sw[i])));
+                dst[2 * i + 1] = rbf(rbf(x1 * hi_bf(cw[i])) + rbf(y1 * hi_bf(sw[i])));
+            }
+        };
+        rot(row, qv);
+        rot(row + H * DEC_HD, kn);
+        vnew = *(const uint4*)(row + 2 * H * DEC_HD + 8 * c);
+        if (ks == 0) {                              // append for the following steps
+            uint4 kw;
+            kw.x = pack2bf(kn[0], kn[1]); kw.y = pack2bf(kn[2], kn[3]); kw.z = pack2bf(kn[4], kn[5]); kw.w = pack2bf(kn[6], kn[7]);
+            *(uint4*)(kb + (size_t)past * DEC_HD + 8 * c) = kw;
+            *(uint4*)(vb + (size_t)past * DEC_HD + 8 * c) = vnew;
+        }
+    }
+    // scores: cached keys from HBM, the new key (j == past) from registers
+    float lmax = -INFINITY;
+    for (int j = ks; j < kv_len; j += 16) {
+        float d = 0.f;
+        if (j < past) {
+            const uint4 u = *(const uint4*)(kb + (size_t)j * DEC_HD + 8 * c);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d += qv[2 * i] * lo_bf(w[i]) + qv[2 * i + 1] * hi_bf(w[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d += qv[2 * i] * kn[2 * i] + qv[2 * i + 1] * kn[2 * i + 1];
+        }
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+        d *= scale;
+        if (c == 0) sc[j] = d;
+        lmax = fmaxf(lmax, d);
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) wred[wave] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    __syncthreads();
+    float lsum = 0.f;
+    for (int j = tid; j < kv_len; j += 256) {
+        const float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) wred[wave] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / (wred[0] + wred[1] + wred[2] + wred[3]);
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = ks; j < kv_len; j += 16) {
+        const float pj = rbf(sc[j] * inv);
+        const uint4 u = (j < past) ? *(const uint4*)(vb + (size_t)j * DEC_HD + 8 * c) : vnew;
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o[2 * i] += pj * lo_bf(w[i]); o[2 * i + 1] += pj * hi_bf(w[i]); }
@@ -464,6 +575,7 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_nt") && (value == 0 || value == 1)) { g_skinny_nt = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value == 0 || value == 1 || value == 2)) { g_skinny_r = value; return SEEDMI_OK; }
+    if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
     return SEEDMI_E_SHAPE;
 }
 
@@ -528,6 +640,34 @@ extern "C" int seedmi_pack_skinny_weights(const void* W, int ldw, int N, int K, 
     hipLaunchKernelGGL(pack_skinny_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ldw, N, K,
                        (bf16_t*)out);
     return seedmi_check_launch("pack_skinny_weights");
+}
+
+extern "C" int seedmi_llama_decode_attention_bf16(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t,
+                                                  const void* sin_t, void* k_cache, void* v_cache, void* out, int ldo, int B,
+                                                  int H, int hd, int tmax, int past_len, float scale, int out_packed,
+                                                  const void* past_len_dev, void* stream) {
+    if (hd != DEC_HD || B <= 0 || H <= 0 || past_len < 0 || past_len + 1 > tmax || (ldqkv % 8) ||
+        (((uintptr_t)qkv | (uintptr_t)cos_t | (uintptr_t)sin_t | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)) {
+        seedmi_set_error("seedmi_llama_decode_attention_bf16: B=%d H=%d hd=%d (must be 128) past=%d tmax=%d ldqkv=%d", B, H, hd,
+                         past_len, tmax, ldqkv);
+        return SEEDMI_E_SHAPE;
+    }
+    const int lds_len = ((past_len_dev ? tmax : past_len + 1) + 3) & ~3;
+    const size_t lds = (size_t)(lds_len + 16 * DEC_HD) * sizeof(float);
+    if (lds > 150 * 1024) {
+        seedmi_set_error("seedmi_llama_decode_attention_bf16: kv_len %d too long for the decode kernel", lds_len);
+        return SEEDMI_E_SHAPE;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_decode_rope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_decode_rope_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv,
+                       (const long long*)pos_ids_i64, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
+                       (bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, past_len, scale, out_packed, lds_len,
+                       (const int*)past_len_dev);
+    return seedmi_check_launch("attn_decode_rope");
 }
 
 extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k_cache, const void* v_cache, void* out,
@@ -621,10 +761,17 @@ extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const vo
         if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, M, h, stream));
         else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, h, M, h, stream));
         CK(linear(M, 3 * h, h, t.xn, h, L.qkv_w, L.qkv_wp, nullptr, 0, EPI_NONE, t.qkv, 3 * h, stream, pk, 0));
-        CK(seedmi_rope_kv_append(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, t.q, h, L.k_cache,
-                                 L.v_cache, batch, T, H, hd, w->tmax, past_len, past_len_dev, stream));
-        CK(seedmi_llama_attention_bf16(t.q, h, L.k_cache, L.v_cache, t.att, h, batch, T, H, hd, w->tmax, past_len, scale,
-                                       pk, past_len_dev, stream));
+        if (T == 1 && g_decode_fused) {
+            // RoPE + cache append + attention in one launch (bit-identical to the two-kernel form below)
+            CK(seedmi_llama_decode_attention_bf16(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, L.k_cache,
+                                                  L.v_cache, t.att, h, batch, H, hd, w->tmax, past_len, scale, pk, past_len_dev,
+                                                  stream));
+        } else {
+            CK(seedmi_rope_kv_append(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, t.q, h, L.k_cache,
+                                     L.v_cache, batch, T, H, hd, w->tmax, past_len, past_len_dev, stream));
+            CK(seedmi_llama_attention_bf16(t.q, h, L.k_cache, L.v_cache, t.att, h, batch, T, H, hd, w->tmax, past_len, scale,
+                                           pk, past_len_dev, stream));
+        }
         CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
         if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, M, h, stream));
         else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, h, M, h, stream));

@@ -78,6 +78,8 @@ SIGNATURES = {
     "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "seedmi_add_i32": (_i, [_vp, _i, _vp]),
     "seedmi_llama_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp, _vp]),
+    "seedmi_llama_decode_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp,
+                                                _vp]),
     "seedmi_gemm_skinny_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "seedmi_pack_skinny_weights_bytes": (C.c_size_t, [_i, _i]),
     "seedmi_pack_skinny_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -86,6 +88,7 @@ SIGNATURES = {
     "seedmi_tokenize_workspace_bytes": (C.c_size_t, [C.POINTER(TokenizerWeights), _i]),
     "seedmi_tokenize": (_i, [C.POINTER(TokenizerWeights), _vp, _i, _i, _vp, C.POINTER(TokenizerTaps), _vp,
                              C.c_size_t, _vp]),
+    "seedmi_sample_token_bf16": (_i, [_vp, _i, _i, _i, C.c_float, C.c_float, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "seedmi_bench_stream_read": (_i, [_vp, C.c_size_t, _i, _vp, _vp]),
     "seedmi_preprocess_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "seedmi_preprocess_image_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -412,6 +412,43 @@ def test_rope_and_llama_attention(lib, B, T, H, past):
     assert_close_bf16(out, want, f"llama_attention B{B} T{T} past{past}", atol_ulps=2.5, frac=0.995)
 
 
+@pytest.mark.parametrize("B,H,past,dev_len,packed", [(3, 4, 0, False, False), (2, 2, 37, False, False), (32, 2, 100, True, True),
+                                                      (17, 3, 126, True, False)])
+def test_fused_decode_attention_equals_rope_then_attention(lib, B, H, past, dev_len, packed):
+    """seedmi_llama_decode_attention_bf16 (RoPE + cache append + attention, one launch) against the two-kernel form on the same
+    inputs: rotated key / value rows in the cache and the attention output must be BIT-identical, with the cache length as
+    a launch argument or read from device memory, row-major or fragment-major output."""
+    hd, tmax, T = 128, 128, 1
+    gen = torch.Generator().manual_seed(1000 + B + past)
+    h = H * hd
+    cos_t, sin_t = _rope_tables(tmax, hd)
+    cos_d, sin_d = cos_t.cuda(), sin_t.cuda()
+    kc = torch.zeros(B, H, tmax, hd, dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    kc[:, :, :past] = bf(rand(gen, B, H, past, hd)).cuda()
+    vc[:, :, :past] = bf(rand(gen, B, H, past, hd)).cuda()
+    kc2, vc2 = kc.clone(), vc.clone()
+    qkv = bf(rand(gen, B, 3 * h)).cuda()
+    past_d = torch.tensor([past], dtype=torch.int32, device="cuda") if dev_len else None
+    pos = None if dev_len else torch.full((B, 1), past, dtype=torch.int64, device="cuda")
+    scale = 1.0 / math.sqrt(hd)
+    rows = (B + 15) // 16 * 16 if packed else B
+    q_out = torch.empty(B, h, dtype=torch.bfloat16, device="cuda")
+    out_a = torch.zeros(rows, h, dtype=torch.bfloat16, device="cuda")
+    out_b = torch.zeros(rows, h, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.seedmi_rope_kv_append(L.ptr(qkv), 3 * h, L.ptr(pos), L.ptr(cos_d), L.ptr(sin_d), L.ptr(q_out), h, L.ptr(kc),
+                                      L.ptr(vc), B, T, H, hd, tmax, past, L.ptr(past_d), L.stream_ptr()), "rope")
+    L.check(lib.seedmi_llama_attention_bf16(L.ptr(q_out), h, L.ptr(kc), L.ptr(vc), L.ptr(out_a), h, B, T, H, hd, tmax, past, scale,
+                                            1 if packed else 0, L.ptr(past_d), L.stream_ptr()), "attention")
+    L.check(lib.seedmi_llama_decode_attention_bf16(L.ptr(qkv), 3 * h, L.ptr(pos), L.ptr(cos_d), L.ptr(sin_d), L.ptr(kc2), L.ptr(vc2),
+                                                   L.ptr(out_b), h, B, H, hd, tmax, past, scale, 1 if packed else 0, L.ptr(past_d),
+                                                   L.stream_ptr()), "fused decode attention")
+    torch.cuda.synchronize()
+    assert torch.equal(kc, kc2) and torch.equal(vc, vc2), "cache append differs"
+    assert torch.equal(out_a, out_b), "attention output differs"
+    assert out_b.float().abs().sum() > 0
+
+
 def test_embed_rows(lib):
     gen = torch.Generator().manual_seed(2)
     table = bf(rand(gen, 1000, 256)).cuda()
