@@ -159,27 +159,45 @@ class LlamaEngine:
         L.check(rc, "seedmi_llama_forward_ex")
         L.check(self.lib.seedmi_add_i32(L.ptr(counter), 1, L.stream_ptr()), "seedmi_add_i32")
 
-    def capture_decode_graph(self, first_tok: torch.Tensor, n_new: int):
-        """Capture one greedy single-token step (forward + argmax + bookkeeping) as a hipGraph, starting from the
-        engine's current cache length.  Returns (replay, out) where ``replay(k)`` runs k further steps (stream ordered)
-        and ``out`` [B, n_new] receives the tokens (column 0 = first_tok)."""
+    def select_token(self, logits: torch.Tensor, tok_out: torch.Tensor, top_p: float = 0.0, temperature: float = 1.0,
+                     uniforms: Optional[torch.Tensor] = None, step_dev: Optional[torch.Tensor] = None, step_offset: int = 0,
+                     history: Optional[torch.Tensor] = None):
+        """seedmi_sample_token_bf16 on logits [B, ld] (bf16): greedy (uniforms None / top_p 0) or temperature + top-p with
+        the uniform for (step, row) taken from ``uniforms`` [steps, B]; writes tok_out [B] and history[:, step]."""
+        B = logits.shape[0]
+        if logits.dtype != torch.bfloat16 or logits.stride(-1) != 1 or tok_out.dtype != torch.int64:
+            raise ValueError("select_token: logits must be bf16 rows, tok_out int64")
+        with torch.cuda.device(self.device):
+            rc = self.lib.seedmi_sample_token_bf16(L.ptr(logits), logits.stride(0), B, self.cfg.vocab, float(temperature),
+                                                   float(top_p), L.ptr(uniforms), L.ptr(step_dev), int(step_offset),
+                                                   L.ptr(tok_out), L.ptr(history), 0 if history is None else history.stride(0),
+                                                   L.stream_ptr())
+        L.check(rc, "seedmi_sample_token_bf16")
+
+    def capture_decode_graph(self, first_tok: torch.Tensor, n_new: int, top_p: float = 0.0, temperature: float = 1.0,
+                             uniforms: Optional[torch.Tensor] = None):
+        """Capture one single-token step (forward, token selection, bookkeeping — all seedmi kernels) as a hipGraph,
+        starting from the engine's current cache length.  Returns (replay, out): ``replay(k)`` runs k further steps
+        (stream ordered, no host sync) and ``out`` [B, n_new] receives the tokens (column 0 = first_tok).  Greedy by
+        default; with ``uniforms`` [n_new, B] (fp32 in [0,1), row s drives column s) the step samples top-p."""
         B = first_tok.shape[0]
         if self.past_len + n_new - 1 > self.tmax:
             raise L.SeedmiError(f"decode would exceed the KV cache ({self.past_len}+{n_new - 1} > {self.tmax})")
+        if uniforms is not None and (tuple(uniforms.shape) != (n_new, B) or uniforms.dtype != torch.float32 or
+                                     uniforms.device != self.device or not uniforms.is_contiguous()):
+            raise ValueError("uniforms must be a contiguous float32 [n_new, B] tensor on the engine's device")
         tok = first_tok.to(torch.int64).reshape(B, 1).contiguous().clone()
         out = torch.zeros(B, n_new, dtype=torch.int64, device=self.device)
         out[:, 0:1] = tok
-        counter = torch.tensor([self.past_len], dtype=torch.int32, device=self.device)
+        past0 = self.past_len
+        counter = torch.tensor([past0], dtype=torch.int32, device=self.device)
         logits = torch.empty(B, self.vocab_pad, dtype=torch.bfloat16, device=self.device)
         ws = self._workspace(B, 1)
-        step_idx = torch.zeros(1, dtype=torch.int64, device=self.device)
 
         def body():
+            # after the step the counter reads past0 + s for the s-th new token: column / uniform row s = counter - past0
             self._decode_step_graphed(tok, logits, counter, ws)
-            nxt = logits[:, :self.cfg.vocab].float().argmax(-1, keepdim=True)
-            tok.copy_(nxt)
-            step_idx.add_(1)
-            out.scatter_(1, step_idx.expand(B, 1), nxt)
+            self.select_token(logits, tok, top_p, temperature, uniforms, counter, -past0, out)
 
         # warm-up on a side stream (required before capture), then rewind its side effects
         side = torch.cuda.Stream(device=self.device)
@@ -191,11 +209,10 @@ class LlamaEngine:
         tok.copy_(tok0)
         counter.copy_(cnt0)
         out.copy_(out0)
-        step_idx.zero_()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body()
-        keep = (tok, counter, logits, ws, step_idx)          # buffers referenced by the graph
+        keep = (tok, counter, logits, ws, uniforms)          # buffers referenced by the graph
 
         def replay(k: int):
             for _ in range(k):
@@ -205,15 +222,29 @@ class LlamaEngine:
         return replay, out
 
     def greedy_decode_graph(self, prompt_ids: torch.Tensor, n_new: int):
-        """Greedy decode with the per-token step captured once as a hipGraph and replayed: ~290 kernel launches per
+        """Greedy decode with the per-token step captured once as a hipGraph and replayed: ~260 kernel launches per
         step collapse into one graph launch (the decode step is launch/HBM bound; the reference additionally syncs
         the host once per layer per step, llama_xformer.py:255).  Returns tokens [B, n_new]."""
+        return self.sample_decode_graph(prompt_ids, n_new, top_p=0.0)
+
+    def sample_decode_graph(self, prompt_ids: torch.Tensor, n_new: int, top_p: float = 0.5, temperature: float = 1.0,
+                            generator: Optional[torch.Generator] = None):
+        """generate(do_sample=True, top_p, temperature) for the scripts' generation_config
+        (scripts/seed_llama_inference_8B.py:81-87) entirely on the device: prefill, then the captured step
+        (forward + top-p draw) replayed n_new - 1 times.  top_p == 0 selects greedily.  The uniforms are drawn up front
+        from ``generator`` (device generator; default = torch's global one), one per (step, row)."""
         self.reset()
+        B = prompt_ids.shape[0]
+        uniforms = None
+        if top_p > 0.0:
+            uniforms = torch.rand(n_new, B, dtype=torch.float32, device=self.device, generator=generator)
         logits0 = self.forward(prompt_ids, last_only=True)
-        tok = logits0[:, 0].float().argmax(-1, keepdim=True)
+        tok = torch.empty(B, dtype=torch.int64, device=self.device)
+        self.select_token(logits0[:, 0], tok, top_p, temperature, uniforms, None, 0, None)
+        tok = tok.view(B, 1)
         if n_new == 1:
             return tok
-        replay, out = self.capture_decode_graph(tok, n_new)
+        replay, out = self.capture_decode_graph(tok, n_new, top_p, temperature, uniforms)
         replay(n_new - 1)
         return out
 

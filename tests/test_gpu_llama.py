@@ -88,3 +88,42 @@ def test_graph_decode_equals_eager_decode():
     torch.cuda.synchronize()
     assert torch.equal(eager, graphed)
     assert eng.past_len == 10 + 8
+
+
+def test_sampled_graph_decode_is_reproducible_and_stays_in_the_nucleus():
+    """generate(do_sample=True, top_p=0.5) on the device: the captured step (forward + seedmi_sample_token_bf16) replayed from
+    a hipGraph gives exactly the tokens of an eager loop fed the same uniforms, and every drawn token lies in the top-p
+    nucleus of the logits it was drawn from (checked with the sampling oracle)."""
+    from oracle import sample_oracle as S
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=9, norm_jitter=0.05)
+    B, T0, n_new, top_p = 3, 10, 9, 0.5
+    ids = torch.randint(3, cfg.vocab, (B, T0), generator=torch.Generator().manual_seed(4)).cuda()
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=64)
+    g = torch.Generator(device="cuda").manual_seed(123)
+    graphed = eng.sample_decode_graph(ids, n_new, top_p=top_p, temperature=1.0, generator=g).clone()
+    torch.cuda.synchronize()
+    assert eng.past_len == T0 + n_new - 1
+    # eager replay with the same uniforms
+    u = torch.rand(n_new, B, dtype=torch.float32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(123))
+    eng.reset()
+    logits = eng.forward(ids, last_only=True)
+    tok = torch.empty(B, dtype=torch.int64, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eager = []
+    for s in range(n_new):
+        step.fill_(s)
+        eng.select_token(logits[:, 0], tok, top_p, 1.0, u, step, 0, None)
+        torch.cuda.synchronize()
+        row_logits = logits[:, 0].float().cpu().numpy()
+        for b in range(B):
+            order, n, _ = S.top_p_keep(row_logits[b], 1.0, top_p)
+            assert int(tok[b]) in set(order[:n + 1].tolist()), (s, b)
+        eager.append(tok.clone())
+        if s + 1 < n_new:
+            logits = eng.forward(tok.view(B, 1), last_only=True)
+    assert torch.equal(torch.stack(eager, dim=1), graphed)
+    # a different seed gives a different continuation; top_p = 0 is the greedy path
+    other = eng.sample_decode_graph(ids, n_new, top_p=top_p, generator=torch.Generator(device="cuda").manual_seed(7))
+    assert not torch.equal(other, graphed)
+    assert torch.equal(eng.sample_decode_graph(ids, n_new, top_p=0.0), eng.greedy_decode(ids, n_new)[0])
