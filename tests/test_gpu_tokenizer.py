@@ -120,3 +120,35 @@ def test_batch_independence_and_raggedness():
     singles = torch.cat([eng.encode(img[i:i + 1]) for i in range(5)], 0)
     assert torch.equal(ids, singles)
     assert torch.equal(eng.encode(img[1:4]), ids[1:4])
+
+
+def test_full_size_batch256_properties():
+    """BASELINE.json's own configuration (full SEED-2 tokenizer, 256 images per GPU) through size-independent properties, since
+    the oracle needs ~1 s per image: the result is deterministic, every row of the 256-batch (two sub-batches on two streams)
+    is bit-identical to the same image run alone or in a small batch (pure map = the DP sharding property), the sub-batch
+    split does not change a single id, and the ids are valid codes that actually use the codebook."""
+    from seed_amd import lib as L
+    cfg = C.SEED2
+    sd = make_tokenizer_state_dict(cfg, seed=0, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    img = torch.randn(256, 3, 224, 224, generator=gen, device="cuda").bfloat16()
+    eng = TokenizerEngine(sd, cfg)
+    t = {}
+    eng.encode(img[:8], t)
+    eng.set_codebook(calibrate_codebook(t["z"].float().cpu(), cfg.n_embed, seed=7))
+    ids = eng.encode(img)
+    torch.cuda.synchronize()
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == (256, cfg.n_query)
+    assert int(ids.min()) >= 0 and int(ids.max()) < cfg.n_embed
+    assert torch.unique(ids).numel() > 32                       # not collapsed onto a handful of codes
+    assert torch.equal(eng.encode(img), ids)                    # deterministic
+    for lo, hi in ((0, 1), (127, 130), (128, 131), (250, 256)):  # rows on both sides of the sub-batch boundary
+        assert torch.equal(eng.encode(img[lo:hi]), ids[lo:hi]), (lo, hi)
+    lib = L.load()
+    try:
+        L.check(lib.seedmi_set_option(b"tokenize_streams", 1), "set_option")
+        assert torch.equal(eng.encode(img), ids)                # one stream == two streams
+        L.check(lib.seedmi_set_option(b"tokenize_streams", 4), "set_option")
+        assert torch.equal(eng.encode(img), ids)
+    finally:
+        lib.seedmi_set_option(b"tokenize_streams", 2)
