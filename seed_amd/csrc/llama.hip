@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
 int g_skinny_nt = 1, g_skinny_nw = 0;
 
 int g_skinny_r = 0;
+int g_prefill_tiled = 1;             // seedmi_set_option("prefill_tiled", 0|1): LDS-tiled prefill attention (0 = first-round kernel)
 int g_decode_fused = 1;              // seedmi_set_option("decode_fused", 0|1): RoPE + KV append folded into decode attention
 
 template <int EPI, int NW, bool NT, bool PACKED, int R>
@@ -569,6 +570,202 @@ int linear(int M, int N, int K, const void* A, int lda, const void* W, const voi
     return seedmi_gemm_bf16(M, N, K, A, lda, W, K, nullptr, R, ldr, epi, C, ldc, 0, 0, s);
 }
 
+// ------------------------------------------------------------------------------------------------ prefill attention, tiled
+// Workgroup = (batch, head, 128 queries), wave = 32 queries (two 16-query MFMA tiles sharing every K / V fragment).  Keys stream
+// through LDS in 64-key tiles: K and V rows (256 B) land by LDS-DMA one tile ahead, double buffered, one barrier per tile; the
+// 16-byte chunk index of a row is XOR-ed with (row & 15) on the DMA source address, so both the K fragment reads (16 rows x
+// 16 B) and the transposing V reads (ds_read_b64_tr_b16, 4 rows x 32 B per lane group) touch every bank equally.
+// S^T = K Q^T puts a lane's scores on keys {4g + r}: two key tiles concatenate into the 8-deep k index of the P^T operand,
+// and the V^T operand reads the same key permutation, so P never leaves registers.  Two passes like the kernel above
+// (P normalised before the bf16 rounding), both from LDS.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr int PT = 64;                       // keys per tile
+constexpr int PT_BYTES = PT * DEC_HD * 2;    // 16 KiB
+
+SEEDMI_DEVINL void glds16_l(const bf16_t* gptr, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_prefill_tiled_kernel(const bf16_t* __restrict__ q, int ldq,
+                                                                    const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                                                    bf16_t* __restrict__ out, int ldo, int T, int H, int tmax,
+                                                                    int past_len, float scale) {
+    __shared__ __attribute__((aligned(16))) char sm[4 * PT_BYTES];          // K0 K1 V0 V1
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qblocks = (T + 127) / 128;
+    const int qb = blockIdx.x % qblocks;
+    const int bh = blockIdx.x / qblocks;
+    const int b = bh / H, h = bh % H;
+    const bf16_t* kb = kc + ((size_t)b * H + h) * tmax * DEC_HD;
+    const bf16_t* vb = vc + ((size_t)b * H + h) * tmax * DEC_HD;
+    const int kv_len = past_len + T;
+    const int q0 = 128 * qb + 32 * wave;                                     // first query of this wave
+    const int wave_lim = min(kv_len - 1, past_len + q0 + 31);                // last key any lane of the wave sees
+    const int blk_lim = min(kv_len - 1, past_len + 128 * qb + 127);
+    const int ntile = blk_lim / PT + 1;
+
+    bf16x8 qf[2][4];
+    int qlim[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qrow = q0 + 16 * u + li;
+        qlim[u] = past_len + qrow;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qrow < T) v = *(const uint4*)(q + ((size_t)b * T + qrow) * ldq + h * DEC_HD + 32 * ks + 8 * g);
+            qf[u][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    // LDS-DMA of one 64-key tile of K or V: wave w copies pieces 4w .. 4w+3 (4 rows of 256 B each)
+    auto stage = [&](const bf16_t* base, char* dst, int t) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int piece = 4 * wave + pc;
+            const int row = 4 * piece + (lane >> 4);
+            const int key = min(PT * t + row, kv_len - 1);
+            const int chunk = (lane & 15) ^ (row & 15);
+            glds16_l(base + (size_t)key * DEC_HD + 8 * chunk, dst + piece * 1024);
+        }
+    };
+    // S^T of this wave's two query tiles against key tile kt4 (16 keys) of the K buffer
+    auto scores = [&](const char* kbuf, int kt4, f32x4 (&s)[2]) {
+        bf16x8 kf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            kf[ks] = *(const bf16x8*)(kbuf + (16 * kt4 + li) * 256 + (((4 * ks + g) ^ li) << 4));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            s[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[u][ks], s[u], 0, 0, 0);
+        }
+    };
+
+    // ---- pass 1: per-lane running max / sum over its keys {16 kt + 4g + r}
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    stage(kb, sm, 0);
+    for (int t = 0; t < ntile; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntile) stage(kb, sm + ((t + 1) & 1) * PT_BYTES, t + 1);
+        if (PT * t > wave_lim) continue;                                     // (wave-uniform) fully masked for this wave
+        const char* kbuf = sm + (t & 1) * PT_BYTES;
+#pragma unroll
+        for (int kt4 = 0; kt4 < 4; ++kt4) {
+            f32x4 s[2];
+            scores(kbuf, kt4, s);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float tm = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = PT * t + 16 * kt4 + 4 * g + r;
+                    s[u][r] = (key <= qlim[u] && key < kv_len) ? s[u][r] * scale : -INFINITY;
+                    tm = fmaxf(tm, s[u][r]);
+                }
+                const float mn = fmaxf(m_run[u], tm);
+                if (mn > -INFINITY) {
+                    float add = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) add += __expf(s[u][r] - mn);
+                    l_run[u] = l_run[u] * __expf(m_run[u] - mn) + add;
+                    m_run[u] = mn;
+                }
+            }
+        }
+    }
+    float mx[2], inv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float m = fmaxf(m_run[u], __shfl_xor(m_run[u], 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float lsum = (m_run[u] > -INFINITY) ? l_run[u] * __expf(m_run[u] - m) : 0.f;
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        mx[u] = m;
+        inv[u] = lsum > 0.f ? 1.0f / lsum : 0.f;
+    }
+
+    // ---- pass 2: P = exp(S - max) / sum rounded to bf16, O^T += V^T P^T
+    f32x4 o[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) o[u][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                                         // pass 1's last tile fully consumed
+    stage(kb, sm, 0);
+    stage(vb, sm + 2 * PT_BYTES, 0);
+    for (int t = 0; t < ntile; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntile) {
+            stage(kb, sm + ((t + 1) & 1) * PT_BYTES, t + 1);
+            stage(vb, sm + (2 + ((t + 1) & 1)) * PT_BYTES, t + 1);
+        }
+        if (PT * t > wave_lim) continue;
+        const char* kbuf = sm + (t & 1) * PT_BYTES;
+        const char* vbuf = sm + (2 + (t & 1)) * PT_BYTES;
+        bf16x8 pf[2][2];                                                     // [query tile][32-key step]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            float pv[2][8];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 s[2];
+                scores(kbuf, 2 * kk + hf, s);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = PT * t + 32 * kk + 16 * hf + 4 * g + r;
+                        pv[u][4 * hf + r] = (key <= qlim[u] && key < kv_len) ? __expf(s[u][r] * scale - mx[u]) * inv[u] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                uint4 pw;
+                pw.x = pack2bf(pv[u][0], pv[u][1]); pw.y = pack2bf(pv[u][2], pv[u][3]);
+                pw.z = pack2bf(pv[u][4], pv[u][5]); pw.w = pack2bf(pv[u][6], pv[u][7]);
+                pf[u][kk] = __builtin_bit_cast(bf16x8, pw);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                // V^T fragment: hd rows 16n + li, keys (g, j) = 32kk + 16 (j >> 2) + 4g + (j & 3): two transposing 8-byte reads
+                const int row = 32 * kk + 4 * g + (li >> 2);
+                const int c = 2 * n + ((li & 3) >> 1);
+                const char* vp0 = vbuf + row * 256 + ((c ^ (row & 15)) << 4) + ((li & 1) << 3);
+                const char* vp1 = vbuf + (row + 16) * 256 + ((c ^ ((row + 16) & 15)) << 4) + ((li & 1) << 3);
+                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp0);
+                const s16x4 cc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp1);
+                const uint2 lo = __builtin_bit_cast(uint2, a), hi = __builtin_bit_cast(uint2, cc);
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) o[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kk], o[u][n], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qrow = q0 + 16 * u + li;
+        if (qrow < T) {
+            bf16_t* op = out + ((size_t)b * T + qrow) * ldo + h * DEC_HD;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                uint2 w;
+                w.x = pack2bf(o[u][n][0], o[u][n][1]);
+                w.y = pack2bf(o[u][n][2], o[u][n][3]);
+                *(uint2*)(op + 16 * n + 4 * g) = w;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int seedmi_llama_set_option(const char* key, int value) {
@@ -576,6 +773,7 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value == 0 || value == 1 || value == 2)) { g_skinny_r = value; return SEEDMI_OK; }
     if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
+    if (!strcmp(key, "prefill_tiled") && (value == 0 || value == 1)) { g_prefill_tiled = value; return SEEDMI_OK; }
     return SEEDMI_E_SHAPE;
 }
 
@@ -708,6 +906,12 @@ extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k
                            (const bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, kv_len, scale, out_packed, lds_len,
                            (const int*)past_len_dev);
         return seedmi_check_launch("attn_decode");
+    }
+    if (g_prefill_tiled) {
+        const int qb128 = (T + 127) / 128;
+        hipLaunchKernelGGL(attn_prefill_tiled_kernel, dim3(B * H * qb128), dim3(256), 0, s, (const bf16_t*)q, ldq,
+                           (const bf16_t*)k_cache, (const bf16_t*)v_cache, (bf16_t*)out, ldo, T, H, tmax, past_len, scale);
+        return seedmi_check_launch("attn_prefill_tiled");
     }
     const int qblocks = (T + 63) / 64;
     hipLaunchKernelGGL(attn_prefill_kernel, dim3(B * H * qblocks), dim3(256), 0, s, (const bf16_t*)q, ldq,

@@ -362,9 +362,18 @@ def _ref_rope(x, cos, sin):
     return r(r(x * cos) + r(rot * sin))
 
 
-@pytest.mark.parametrize("B,T,H,past", [(2, 12, 2, 0), (3, 1, 4, 9), (2, 70, 2, 0), (1, 5, 2, 7)])
-def test_rope_and_llama_attention(lib, B, T, H, past):
-    hd, tmax = 128, 128
+@pytest.fixture(params=[1, 0], ids=["prefill_tiled", "prefill_v1"])
+def prefill_variant(request, lib):
+    """Prefill attention runs once per kernel: the LDS-tiled one (default) and the first-round direct-from-L2 one."""
+    L.check(lib.seedmi_set_option(b"prefill_tiled", request.param), "set_option")
+    yield request.param
+    lib.seedmi_set_option(b"prefill_tiled", 1)
+
+
+@pytest.mark.parametrize("B,T,H,past", [(2, 12, 2, 0), (3, 1, 4, 9), (2, 70, 2, 0), (1, 5, 2, 7), (1, 649, 2, 0), (2, 130, 1, 63),
+                                        (1, 128, 1, 0), (1, 129, 3, 1)])
+def test_rope_and_llama_attention(lib, prefill_variant, B, T, H, past):
+    hd, tmax = 128, max(128, past + T)
     gen = torch.Generator().manual_seed(B * 10 + T)
     h = H * hd
     cos_t, sin_t = _rope_tables(tmax, hd)
