@@ -977,12 +977,16 @@ int launch_gemm128(const GemmParams& p, hipStream_t stream) {
 }
 
 int g_gemm_variant = 0;      // 0 = auto, 128 / 256 = force a kernel (seedmi_set_option("gemm", v))
+int g_gemm_min_tiles = 160;    // seedmi_set_option("gemm_min_tiles", n)
 
 template <int EPI>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
-    const bool big = p.M >= 1024 && p.N >= 256;
-    if (g_gemm_variant == 232) return launch_gemm256x<EPI>(p, s);
-    if (g_gemm_variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves          // 256x256 tile on v_mfma_f32_32x32x16_bf16
+    // the 256x256 kernel wants at least g_gemm_min_tiles tiles (one per CU is 256): below that the 128x128 kernel's four times
+    // finer tiling fills the chip better (Q-Former GEMMs at M = B*32)
+    const long long tiles256 = (long long)((p.M + B2 - 1) / B2) * ((p.N + B2 - 1) / B2);
+    const bool big = p.M >= 1024 && p.N >= 256 && tiles256 >= g_gemm_min_tiles;
+    if (g_gemm_variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
+    if (g_gemm_variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
     const bool use256 = g_gemm_variant == 256 || (g_gemm_variant == 0 && big && SEEDMI_GEMM256_DEFAULT);
     return use256 ? launch_gemm256<EPI>(p, s) : launch_gemm128<EPI>(p, s);
 }
@@ -996,6 +1000,10 @@ extern "C" int seedmi_set_option(const char* key, int value) {
     }
     if (key && !strcmp(key, "gemm_group_m") && value >= 1 && value <= 64) {
         g_group_m = value;
+        return SEEDMI_OK;
+    }
+    if (key && !strcmp(key, "gemm_min_tiles") && value >= 1 && value <= 4096) {
+        g_gemm_min_tiles = value;
         return SEEDMI_OK;
     }
     if (key && !strcmp(key, "gemm_ablate") && value >= 0 && value <= 31) {
