@@ -220,7 +220,12 @@ def main():
         }
         flops_img = cfg.flops_per_image()
         extra = {"gflop_per_image": round(flops_img / 1e9, 2),
-                 "path_mfma_frac": round(img_s / world * flops_img / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+                 "path_mfma_frac": round(img_s / world * flops_img / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                 # what an MI355X of this pool sustains when nothing but the resource is exercised (SURVEY.md 8d "vs
+                 # measured"): MFMA-only GEMM loop (tools/gemm_ablate.py mask 7) and 16-byte stream read of 8 GiB
+                 # (tools/hbm_read_bench.py); recorded under profiles/, not re-measured here
+                 "measured_ceilings": {"mfma_only_loop_tflops": 1980.0, "hbm_stream_read_gbps": 7180.0,
+                                       "source": "profiles/r01_gemm_loop_ablation.txt, profiles/r01_hbm_stream_read.json"}}
         if world == 1:
             out["roofline"] = qkv_gemm_roofline(B)
             if not args.no_cpu_baseline:
