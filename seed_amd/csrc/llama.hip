@@ -176,10 +176,32 @@ int launch_skinny_r(const SkinnyParams& p, hipStream_t s) {
 
 template <int EPI, int NW, bool NT, bool PACKED>
 int launch_skinny_nw(const SkinnyParams& p, hipStream_t s) {
-    // two row-tiles per workgroup when that still leaves >= 2 workgroups per CU (and the packed tile count is even)
+    // R weight row-tiles (16 rows each) per workgroup.  A memory-bound launch loses whatever part of its last round of workgroups
+    // is empty, so R is chosen for the fullest rounds: R = 1 runs two workgroups per CU (116 VGPRs), R >= 2 one; ties go to the
+    // larger R (each activation fragment is reused R times).  8B QKV: 768 tiles -> R = 3 = exactly one workgroup per CU (+19 %).
     const int tiles = (p.N + 15) / 16;
-    const bool r2 = g_skinny_r == 2 || (g_skinny_r == 0 && tiles >= 1024);
-    if (r2 && (tiles % 2) == 0) return launch_skinny_r<EPI, NW, NT, PACKED, 2>(p, s);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    int best_r = 1;
+    if (g_skinny_r != 0) {
+        best_r = g_skinny_r;
+    } else {
+        double best_eff = 0.0;
+        for (int r = 1; r <= 3; ++r) {
+            if (tiles % r) continue;
+            if (r == 3 && p.M > 32) continue;                       // register budget (two activation row tiles at most)
+            if (r == 2 && tiles < 1024) continue;                   // (measured: R = 2 only pays on the widest projections)
+            const int wgs = tiles / r, slots = n_cu * (r == 1 ? 2 : 1);
+            const double eff = (double)wgs / ((double)((wgs + slots - 1) / slots) * slots);
+            if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && r > best_r)) { best_eff = eff; best_r = r; }
+        }
+    }
+    if (best_r == 3 && (tiles % 3) == 0 && p.M <= 32) return launch_skinny_r<EPI, NW, NT, PACKED, 3>(p, s);
+    if (best_r == 2 && (tiles % 2) == 0) return launch_skinny_r<EPI, NW, NT, PACKED, 2>(p, s);
     return launch_skinny_r<EPI, NW, NT, PACKED, 1>(p, s);
 }
 
@@ -771,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tiled_kernel(const bf16_t
 int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_nt") && (value == 0 || value == 1)) { g_skinny_nt = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
-    if (!strcmp(key, "skinny_rows") && (value == 0 || value == 1 || value == 2)) { g_skinny_r = value; return SEEDMI_OK; }
+    if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
     if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
     if (!strcmp(key, "prefill_tiled") && (value == 0 || value == 1)) { g_prefill_tiled = value; return SEEDMI_OK; }
     return SEEDMI_E_SHAPE;
