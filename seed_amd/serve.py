@@ -1,0 +1,164 @@
+"""Serving shell around the hot path: the request/response contract of the reference's Flask
+``/generate`` endpoint (gradio_demo/seed_llama_flask.py:93-226) on top of the device engines.
+
+Same JSON keys, defaults, assertion and ``error_msg`` texts as the reference handler; what changes is underneath:
+
+* raw images go PIL -> ``DevicePreprocessor`` (bit-exact with the reference's transform) -> ``TokenizerEngine.encode``;
+* the prompt is spliced by id arithmetic (``32000 + code`` between ``<img>`` / ``</img>``) instead of formatting
+  ``<img_XXXXX>`` strings and re-tokenising them (:149-164);
+* ``model.generate(do_sample=True, top_p, temperature)`` (:166-174) is ``LlamaEngine.sample_decode_graph``: prefill, then one
+  captured step (forward + top-p draw) replayed on the device; the output is cut at the first EOS afterwards;
+* generated image spans are turned into unCLIP embeds on the device (``seedmi_detokenize``); rendering pixels needs the
+  diffusers pipeline, which is not part of this library: pass ``image_renderer`` (embeds -> PIL.Image) to get base64 PNGs,
+  otherwise the slot stays '' as it does in the reference when decoding fails.
+
+Transport is left to the caller: ``GenerateService.handle(dict) -> dict`` is the whole handler; ``create_app`` wraps it in a
+FastAPI route when fastapi is installed (the reference uses Flask's dev server, one request at a time; so does this).
+"""
+import base64
+import io
+from typing import Callable, List, Optional
+
+import torch
+
+BOI_TOKEN = '<img>'
+EOI_TOKEN = '</img>'
+IMG_FLAG = '<image>'
+NUM_IMG_TOKNES = 32
+NUM_IMG_CODES = 8192
+IMAGE_ID_SHIFT = 32000
+
+
+def decode_image(encoded_image: str):
+    from PIL import Image
+    return Image.open(io.BytesIO(base64.b64decode(encoded_image.encode('utf-8'))))
+
+
+def encode_image(image, format: str = 'PNG') -> str:
+    with io.BytesIO() as buffer:
+        image.save(buffer, format=format)
+        return base64.b64encode(buffer.getvalue()).decode('utf-8')
+
+
+class GenerateService:
+    """text_tokenizer needs ``bos_token_id``, ``eos_token_id``, ``eos_token`` (str), ``encode(str) -> List[int]`` (no special
+    tokens added) and ``decode(List[int]) -> str`` (special tokens kept: BOI / EOI ids decode to '<img>' / '</img>')."""
+
+    def __init__(self, text_tokenizer, encode_images: Callable[[torch.Tensor], torch.Tensor], llama_engine,
+                 preprocess: Callable, boi_token_id: int = IMAGE_ID_SHIFT + NUM_IMG_CODES,
+                 eoi_token_id: int = IMAGE_ID_SHIFT + NUM_IMG_CODES + 1, codebook_entry: Optional[Callable] = None,
+                 image_renderer: Optional[Callable] = None, device="cuda"):
+        self.tok = text_tokenizer
+        self.encode_images = encode_images          # [B,3,S,S] device tensor -> int64 [B,32]
+        self.llm = llama_engine
+        self.preprocess = preprocess                # PIL.Image -> [3,S,S] device tensor
+        self.boi_token_id, self.eoi_token_id = boi_token_id, eoi_token_id
+        self.codebook_entry = codebook_entry        # int64 [B,32] -> image embeds (seedmi_detokenize)
+        self.image_renderer = image_renderer        # embeds [1,D] -> PIL.Image (the diffusers pipeline, external)
+        self.image_id_shift = IMAGE_ID_SHIFT
+        self.device = device
+
+    # ---- seed_llama_flask.py:96-147: request fields, mixed raw / pre-tokenised images
+    def _image_ids(self, image_list) -> torch.Tensor:
+        tensors, tensor_idx, ids_list, ids_idx = [], [], [], []
+        for idx, item in enumerate(image_list):
+            if isinstance(item, str):
+                tensors.append(self.preprocess(decode_image(item)))
+                tensor_idx.append(idx)
+            else:
+                ids_list.append(item)
+                ids_idx.append(idx)
+        if tensors:
+            ids_1 = self.encode_images(torch.stack(tensors, dim=0)).cpu()
+            num_image_ids = ids_1.shape[-1]
+        else:
+            num_image_ids = len(ids_list[-1])
+        images_ids = torch.zeros((len(image_list), num_image_ids), dtype=torch.long)
+        if tensor_idx:
+            images_ids[tensor_idx, :] = ids_1
+        if ids_idx:
+            images_ids[ids_idx, :] = torch.tensor(ids_list, dtype=torch.long)
+        return images_ids
+
+    def build_prompt(self, text_list: List[str], images_ids: Optional[torch.Tensor], force_boi: bool) -> List[int]:
+        """:149-164 by id arithmetic: BOS, text_0, <img> 32000+ids_0 </img>, text_1, ..., text_n [, <img>]."""
+        ids = [self.tok.bos_token_id]
+        for i, text in enumerate(text_list):
+            ids += self.tok.encode(text) if text else []
+            if images_ids is not None and i < images_ids.shape[0]:
+                ids += [self.boi_token_id] + [self.image_id_shift + int(c) for c in images_ids[i].view(-1).tolist()] + \
+                       [self.eoi_token_id]
+        if force_boi:
+            ids.append(self.boi_token_id)
+        return ids
+
+    def handle(self, request_info: dict) -> dict:
+        text_list = request_info['text'].split(IMG_FLAG)
+        image_list = request_info['images']
+        temperature = request_info.get('temperature', 0.7)
+        num_beams = request_info.get('num_beams', 1)
+        max_new_tokens = request_info.get('max_new_tokens', 256)
+        top_p = request_info.get('top_p', 0.5)
+        force_boi = request_info.get('force_boi', False)
+        assert len(text_list) == len(image_list) + 1
+        if num_beams != 1:
+            raise ValueError("num_beams > 1 is not supported by the on-device sampler (the reference demo always sends 1)")
+
+        images_ids = self._image_ids(image_list) if len(image_list) > 0 else None
+        images_ids_list = images_ids.tolist() if images_ids is not None else []
+        input_ids = self.build_prompt(text_list, images_ids, force_boi)
+        prompt = torch.tensor([input_ids], dtype=torch.int64, device=self.device)
+
+        generate_ids = self.llm.sample_decode_graph(prompt, max_new_tokens, top_p=top_p, temperature=temperature)[0].cpu()
+        eos = torch.where(generate_ids == self.tok.eos_token_id)[0]
+        if len(eos) > 0:                                               # generate() stops at EOS (the EOS token itself is kept)
+            generate_ids = generate_ids[:int(eos[0]) + 1]
+        if force_boi:                                                  # :177-178 the forced <img> counts as generated
+            generate_ids = torch.cat((prompt[0, -1:].cpu(), generate_ids))
+
+        boi_indices = torch.where(generate_ids == self.boi_token_id)[0].tolist()
+        eoi_indices = torch.where(generate_ids == self.eoi_token_id)[0].tolist()
+        generated_image_base64_list = []
+        text_mask = torch.ones_like(generate_ids, dtype=torch.bool)
+        error_msg = []
+        if len(boi_indices) != len(eoi_indices):
+            error_msg.append(
+                f'Num of BOI (begain of image) tokens: {len(boi_indices)} is not equal to EOI(end of image tokens): {len(eoi_indices)}, some image Some images will fail to decode.'
+            )
+        num_images = min(len(boi_indices), len(eoi_indices))
+        for idx in range(num_images):
+            boi_index, eoi_index = boi_indices[idx], eoi_indices[idx]
+            image_ids = generate_ids[boi_index + 1:eoi_index].unsqueeze(0) - self.image_id_shift
+            if image_ids.shape[-1] != NUM_IMG_TOKNES:
+                error_msg.append(f'Len(image_ids) {image_ids.shape[-1]} is not equal to {NUM_IMG_TOKNES}')
+                image_base64 = ''
+            elif (image_ids < 0).any() or (image_ids >= NUM_IMG_CODES).any():
+                error_msg.append(f'Some image_id out of range: [0, {NUM_IMG_CODES})')
+                image_base64 = ''
+            else:
+                image_base64 = ''
+                if self.codebook_entry is not None and self.image_renderer is not None:
+                    embeds = self.codebook_entry(image_ids.to(self.device))
+                    image_base64 = encode_image(self.image_renderer(embeds))
+            generated_image_base64_list.append(image_base64)
+            text_mask[boi_index + 1:eoi_index] = False
+            images_ids_list.append(image_ids.view(-1).tolist())
+        generate_ids = generate_ids[text_mask]
+
+        generate_text = self.tok.decode(generate_ids.tolist())
+        generate_text = generate_text.replace(BOI_TOKEN + ' ' + EOI_TOKEN + ' ', IMG_FLAG)
+        generate_text = generate_text.replace(self.tok.eos_token, '')
+        return {'text': generate_text, 'images': generated_image_base64_list, 'images_ids': images_ids_list,
+                'error_msg': error_msg}
+
+
+def create_app(service: GenerateService):
+    """POST/GET /generate with the reference's JSON body (seed_llama_flask.py:93-96)."""
+    from fastapi import FastAPI, Request
+    app = FastAPI()
+
+    async def generate(request: Request):
+        return service.handle(await request.json())
+
+    app.add_api_route('/generate', generate, methods=['GET', 'POST'])
+    return app

@@ -1,0 +1,127 @@
+"""The /generate contract of gradio_demo/seed_llama_flask.py:93-226 on seed_amd/serve.py, with stub engines on CPU
+(request parsing, mixed raw / pre-tokenised images, id-arithmetic prompt, span parsing, error_msg conventions) and, on the
+GPU, end to end through the real engines at TINY size."""
+import base64
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from seed_amd import serve
+
+BOI, EOI, SHIFT = 32000 + 8192, 32000 + 8193, 32000
+
+
+class CharTokenizer:
+    """One id per character (3 + ord): enough to check where text and image spans land."""
+    bos_token_id, eos_token_id, eos_token = 1, 2, '</s>'
+
+    def encode(self, text):
+        return [3 + ord(c) for c in text]
+
+    def decode(self, ids):
+        out = []
+        for i in ids:
+            out.append({BOI: '<img> ', EOI: '</img> ', 2: '</s>', 1: '<s>'}.get(i, chr(i - 3) if 3 <= i < 3 + 0x110000 else '?'))
+        return ''.join(out)
+
+
+class ScriptedLLM:
+    def __init__(self, script):
+        self.script, self.calls = script, []
+
+    def sample_decode_graph(self, prompt, n_new, top_p=0.5, temperature=1.0, generator=None):
+        self.calls.append(dict(prompt=prompt.clone(), n_new=n_new, top_p=top_p, temperature=temperature))
+        out = torch.full((1, n_new), 2, dtype=torch.int64)
+        out[0, :len(self.script)] = torch.tensor(self.script)
+        return out
+
+
+def _png_b64(h=20, w=30):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.random.RandomState(0).randint(0, 255, (h, w, 3)).astype(np.uint8)).save(buf, format='PNG')
+    return base64.b64encode(buf.getvalue()).decode()
+
+
+def _service(script, **kw):
+    enc = lambda batch: torch.arange(32).repeat(batch.shape[0], 1) + 100          # "tokenizer": ids 100..131 per image
+    pre = lambda pil: torch.zeros(3, 224, 224)
+    return serve.GenerateService(CharTokenizer(), enc, ScriptedLLM(script), pre, device="cpu", **kw)
+
+
+def test_prompt_is_spliced_by_id_arithmetic_and_defaults_match_the_reference():
+    svc = _service([3 + ord('o'), 3 + ord('k'), 2])
+    pre_ids = list(range(7000, 7032))
+    out = svc.handle({'text': 'a<image>b<image>c', 'images': [_png_b64(), pre_ids]})
+    call = svc.llm.calls[0]
+    want = [1, 3 + ord('a'), BOI] + [SHIFT + 100 + i for i in range(32)] + [EOI, 3 + ord('b'), BOI] + \
+           [SHIFT + c for c in pre_ids] + [EOI, 3 + ord('c')]
+    assert call['prompt'][0].tolist() == want
+    assert (call['n_new'], call['top_p'], call['temperature']) == (256, 0.5, 0.7)          # :98-102 defaults
+    assert out['text'] == 'ok' and out['images'] == [] and out['error_msg'] == []
+    assert out['images_ids'] == [[100 + i for i in range(32)], pre_ids]
+
+
+def test_text_and_image_count_must_match():
+    with pytest.raises(AssertionError):
+        _service([2]).handle({'text': 'no flag here', 'images': [list(range(32))]})
+
+
+def test_generated_image_span_is_parsed_and_masked_out_of_the_text():
+    codes = [5 * i for i in range(32)]
+    script = [3 + ord('x'), BOI] + [SHIFT + c for c in codes] + [EOI, 3 + ord('y'), 2, 3 + ord('z')]
+    out = _service(script).handle({'text': 'hi', 'images': [], 'max_new_tokens': 64})
+    assert out['images_ids'] == [codes]
+    assert out['images'] == ['']                      # no renderer attached: the slot stays empty, as when decoding fails
+    assert out['text'] == 'x' + serve.IMG_FLAG + 'y'  # '<img> </img> ' -> '<image>', EOS dropped, nothing after EOS
+    assert out['error_msg'] == []
+
+
+def test_error_msg_conventions():
+    short = [BOI] + [SHIFT + 1] * 5 + [EOI]
+    out = _service(short).handle({'text': 'q', 'images': []})
+    assert out['error_msg'] == ['Len(image_ids) 5 is not equal to 32'] and out['images'] == ['']
+    bad = [BOI] + [SHIFT - 7] + [SHIFT + 1] * 31 + [EOI]
+    out = _service(bad).handle({'text': 'q', 'images': []})
+    assert out['error_msg'] == ['Some image_id out of range: [0, 8192)']
+    unbalanced = [BOI] + [SHIFT + 1] * 32
+    out = _service(unbalanced).handle({'text': 'q', 'images': []})
+    assert out['error_msg'][0].startswith('Num of BOI (begain of image) tokens: 1 is not equal to EOI(end of image tokens): 0')
+
+
+def test_force_boi_counts_the_forced_token_as_generated_and_renderer_hook():
+    codes = list(range(32))
+    script = [SHIFT + c for c in codes] + [EOI, 2]
+    from PIL import Image
+    svc = _service(script, codebook_entry=lambda ids: torch.zeros(ids.shape[0], 1024),
+                   image_renderer=lambda emb: Image.new('RGB', (8, 8), (255, 0, 0)))
+    out = svc.handle({'text': 'draw', 'images': [], 'force_boi': True})
+    assert svc.llm.calls[0]['prompt'][0, -1].item() == BOI
+    assert out['images_ids'] == [codes] and out['error_msg'] == []
+    img = serve.decode_image(out['images'][0])
+    assert img.size == (8, 8)
+
+
+@pytest.mark.gpu
+def test_generate_end_to_end_on_device_engines():
+    """Raw image -> device pre-processing -> tokenizer engine -> spliced prompt -> sampled graph decode -> parsed reply,
+    through the real engines at test size (TINY tokenizer, LLAMA_TINY with the 40194-wide SEED vocabulary)."""
+    import dataclasses
+    from seed_amd import config as C
+    from seed_amd.llama_engine import LlamaEngine
+    from seed_amd.preprocess import DevicePreprocessor, BILINEAR
+    from seed_amd.tokenizer_engine import TokenizerEngine
+    from seed_amd.weights import make_llama_state_dict, make_tokenizer_state_dict
+    tcfg = C.TINY
+    teng = TokenizerEngine(make_tokenizer_state_dict(tcfg, seed=0), tcfg)
+    lcfg = dataclasses.replace(C.LLAMA_TINY, vocab=40194)
+    leng = LlamaEngine(make_llama_state_dict(lcfg, seed=1), lcfg, device="cuda", batch_cap=1, tmax=256)
+    pre = DevicePreprocessor(tcfg.img_size, interpolation=BILINEAR, keep_ratio=False)
+    svc = serve.GenerateService(CharTokenizer(), teng.encode, leng, pre)
+    out = svc.handle({'text': 'look<image>what is it?', 'images': [_png_b64(40, 50)], 'max_new_tokens': 24, 'top_p': 0.5})
+    assert set(out) == {'text', 'images', 'images_ids', 'error_msg'}
+    assert len(out['images_ids']) >= 1 and len(out['images_ids'][0]) == 32
+    assert all(0 <= c < tcfg.n_embed for c in out['images_ids'][0])
+    assert isinstance(out['text'], str)
