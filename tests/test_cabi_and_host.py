@@ -40,6 +40,43 @@ def test_no_compute_without_gpu_is_loud():
         TokenizerEngine({}, C.TINY, device="cuda")
 
 
+def test_argument_validation_returns_status_codes_and_messages():
+    """Every entry point rejects bad shapes / alignment / null pointers with a negative SEEDMI_E_* status and a message in
+    seedmi_last_error() BEFORE touching the device (so this runs without a GPU); the Python layer turns them into exceptions
+    at the points where the reference asserts."""
+    import ctypes as C
+    from seed_amd import lib
+    l = lib.load()
+    fake = C.c_void_p(0x1000)                     # 16-byte aligned, never dereferenced on these paths
+    E_SHAPE, E_ALIGN = -1, -3
+
+    def err():
+        return l.seedmi_last_error().decode()
+
+    assert l.seedmi_gemm_bf16(16, 16, 100, fake, 104, fake, 104, None, None, 0, lib.EPI_BIAS, fake, 16, 0, 0, None) == E_SHAPE
+    assert "multiple of 64" in err()
+    assert l.seedmi_gemm_bf16(16, 16, 64, C.c_void_p(0x1004), 64, fake, 64, None, None, 0, lib.EPI_BIAS, fake, 16, 0, 0, None) == E_ALIGN
+    assert l.seedmi_gemm_bf16(16, 16, 64, fake, 64, fake, 64, None, None, 0, lib.EPI_BIAS_RESIDUAL, fake, 16, 0, 0, None) == E_SHAPE
+    assert "residual" in err()
+    assert l.seedmi_gemm_bf16(16, 16, 64, fake, 64, fake, 64, None, None, 0, 99, fake, 16, 0, 0, None) == E_SHAPE
+    assert "epilogue" in err()
+    assert l.seedmi_attention_bf16(fake, 64, fake, 64, fake, 64, fake, 64, 1, 1, 64, 0, 16, 0.125, 0, 1, None) == E_SHAPE
+    assert l.seedmi_llama_attention_bf16(fake, 128, fake, fake, fake, 128, 1, 1, 1, 96, 64, 0, 0.1, 0, None, None) == E_SHAPE
+    assert "128" in err()
+    assert l.seedmi_gemm_skinny_bf16(65, 64, 128, fake, 128, fake, 128, None, 0, lib.EPI_NONE, fake, 64, None) == E_SHAPE
+    assert l.seedmi_sample_token_bf16(fake, 100, 2, 60000, 1.0, 0.5, None, None, 0, fake, None, 0, None) == E_SHAPE
+    assert l.seedmi_sample_token_bf16(fake, 100, 2, 100, 0.0, 0.5, None, None, 0, fake, None, 0, None) == E_SHAPE       # temperature 0
+    mean = (C.c_float * 3)(0, 0, 0)
+    assert l.seedmi_preprocess_image_u8(fake, 10, 10, 30, 8, 8, 5, 0, 0, 8, 8, mean, mean, fake, 1, None, fake, 1 << 20, None) == E_SHAPE
+    assert l.seedmi_preprocess_image_u8(fake, 10, 10, 30, 8, 8, 3, 4, 0, 8, 8, mean, mean, fake, 1, None, fake, 1 << 20, None) == E_SHAPE
+    assert l.seedmi_preprocess_workspace_bytes(0, 10, 8, 8, 3) == 0
+    assert l.seedmi_detokenize(None, fake, 1, fake, None, fake, 0, None) == E_SHAPE
+    assert l.seedmi_set_option(b"no_such_option", 1) == E_SHAPE and "no_such_option" in err()
+    assert l.seedmi_set_option(b"tokenize_streams", 9) == E_SHAPE
+    with pytest.raises(lib.SeedmiError, match="unknown option"):
+        lib.check(l.seedmi_set_option(b"gemm", 7), "seedmi_set_option")
+
+
 def test_product_path_never_imports_the_oracle():
     for pkg in ("seed_amd", "models"):
         for root, _, files in os.walk(os.path.join(ROOT, pkg)):
