@@ -121,6 +121,16 @@ int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k_cache, con
 /* Skinny GEMM for decode (M <= 64): same contract as seedmi_gemm_bf16 restricted to NONE/BIAS_RESIDUAL/SWIGLU. */
 int seedmi_gemm_skinny_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* residual,
                             int ldr, int epilogue, void* C, int ldc, void* stream);
+/* Decode GEMM with the RMSNorm in front of it folded in (llama_xformer.py:105-113 + the nn.Linear that follows): A holds the
+ * UN-normalised rows (fragment-major when a_packed), W_packed holds weight * gamma; the kernel accumulates the rows' sums of squares
+ * from the activation fragments it streams and scales its fp32 accumulators by rsqrt(mean(x^2) + rms_eps) before the single bf16
+ * rounding.  rms_eps == 0 disables the scaling (plain packed GEMM).  x_packed_out (optional, BIAS_RESIDUAL only) receives a second,
+ * fragment-major copy of the result: the residual stream as the next folded GEMM wants it. */
+int seedmi_gemm_skinny_norm_bf16(int M, int N, int K, const void* A, int a_packed, const void* W_packed, float rms_eps,
+                                 const void* residual, int ldr, int epilogue, void* C, int ldc, int c_packed, void* x_packed_out,
+                                 void* stream);
+/* rows [rows, cols] (row stride ldx) -> the fragment-major activation layout, no arithmetic. */
+int seedmi_pack_activations_bf16(const void* x, int ldx, void* out_packed, int rows, int cols, void* stream);
 /* The same GEMM on fragment-major weights: tile (16 rows) x k-step (32) blocks of 1 KiB laid out in the MFMA operand's
  * lane order, so every wave streams one contiguous region of HBM (row-major weights put the 16 rows of a load on the
  * same channels: 2.3 vs > 4 TB/s).  Pack once per weight with seedmi_pack_skinny_weights. */
@@ -255,6 +265,8 @@ typedef struct {
     const void* lm_head;             /* [vocab_pad, h] (rows >= vocab zero)               */
     const void *cos_t, *sin_t;       /* [max_pos, hd] bf16                                */
     const void* lm_head_p;           /* optional fragment-major lm_head (vocab_pad rows)  */
+    int norm_folded;                 /* 1: qkv_wp / gate_up_wp / lm_head_p hold weight * gamma of the RMSNorm in front of them (input_layernorm,
+                                      * post_attention_layernorm, model.norm): decode steps then run without norm launches */
 } seedmi_llama_weights_t;
 
 size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, int batch, int T);

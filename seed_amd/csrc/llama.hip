@@ -24,11 +24,15 @@ struct SkinnyParams {
     const bf16_t* R; int ldr;
     bf16_t* C; int ldc;
     int a_packed, c_packed;      // activations / SWIGLU output in the fragment-major layout (see norm_misc.hip PACK)
+    // RMSNorm folded into the GEMM (decode chain): A holds the UN-normalised rows, W holds weight * gamma; the kernel sums the
+    // squares of the activation fragments it streams anyway and scales its accumulators by rsqrt(mean(x^2) + eps) per row
+    float norm_eps;              // > 0 enables it
+    bf16_t* xp_out;              // optional second copy of a BIAS_RESIDUAL result in the fragment-major activation layout
 };
 
 // wave 0's epilogue: lane (li, g) owns rows m = 16 t + li and the four columns n0 + 16 r + 4 g .. +3
 template <int MT, int EPI, int R>
-SEEDMI_DEVINL void skinny_epilogue(const SkinnyParams& p, f32x4 (&acc)[R][MT], int n0, int li, int g) {
+SEEDMI_DEVINL void skinny_epilogue(const SkinnyParams& p, f32x4 (&acc)[R][MT], int n0, int li, int g, const float (&rstd)[MT]) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -36,7 +40,7 @@ SEEDMI_DEVINL void skinny_epilogue(const SkinnyParams& p, f32x4 (&acc)[R][MT], i
         const int m = 16 * t + li;
         const int nb_ = n0 + 16 * r + 4 * g;
         if (m >= p.M || nb_ >= p.N) continue;
-        float v[4] = {acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]};
+        float v[4] = {acc[r][t][0] * rstd[t], acc[r][t][1] * rstd[t], acc[r][t][2] * rstd[t], acc[r][t][3] * rstd[t]};
         if (EPI == EPI_BIAS_RESIDUAL) {
             const bf16_t* rp = p.R + (size_t)m * p.ldr + nb_;
 #pragma unroll
@@ -56,6 +60,9 @@ SEEDMI_DEVINL void skinny_epilogue(const SkinnyParams& p, f32x4 (&acc)[R][MT], i
                 w.x = pack2bf(v[0], v[1]);
                 w.y = pack2bf(v[2], v[3]);
                 *(uint2*)cp = w;
+                if (p.xp_out)                                             // the next GEMM's fragment-major A operand (row length N)
+                    *(uint2*)(p.xp_out + ((size_t)((m >> 4) * (p.N >> 5) + (nb_ >> 5)) * 64 + ((nb_ >> 3) & 3) * 16 + (m & 15)) * 8 +
+                              (nb_ & 7)) = w;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) cp[e] = f2bf(v[e]);
@@ -115,6 +122,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
             for (int t = 0; t < MT; ++t) af[u][t] = *(const bf16x8*)(ap[t] + kk * astep);
         }
     };
+    float ss[MT];                                                     // sum of squares of this wave's K slice, rows 16t + li
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ss[t] = 0.f;
+    const bool do_norm = p.norm_eps > 0.f;
     auto compute = [&](bf16x8 (&wf)[U][R], bf16x8 (&af)[U][MT], int b) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -124,6 +135,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
                         acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][r], af[u][t], acc[r][t], 0, 0, 0);
+                if (do_norm) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const uint4 xw = __builtin_bit_cast(uint4, af[u][t]);
+                        const uint32_t w4[4] = {xw.x, xw.y, xw.z, xw.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float lo = lo_bf(w4[i]), hi = hi_bf(w4[i]);
+                            ss[t] = fmaf(lo, lo, fmaf(hi, hi, ss[t]));
+                        }
+                    }
+                }
             }
         }
     };
@@ -133,6 +156,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
         compute(w0, a0, b);
         if (b + 2 < nb) load(w0, a0, b + 2);
         if (b + 1 < nb) compute(w1, a1, b + 1);
+    }
+    __shared__ float red_ss[NW][MT][16];
+    if (do_norm) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {                                // lanes li + 16 g hold the four k-quarters of row 16t + li
+            ss[t] += __shfl_xor(ss[t], 16, 64);
+            ss[t] += __shfl_xor(ss[t], 32, 64);
+            if (g == 0) red_ss[wave][t][li] = ss[t];
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -152,13 +184,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
             for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[r][t][e] += red[w][r][t][lane][e];
-    skinny_epilogue<MT, EPI, R>(p, acc, n0, li, g);
+    float rstd[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        rstd[t] = 1.f;
+        if (do_norm) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += red_ss[w][t][li];        // fixed order: the same rstd in every workgroup
+            rstd[t] = rsqrtf(tot / (float)p.K + p.norm_eps);             // LlamaRMSNorm: variance = mean(x^2) in fp32 (llama_xformer.py:108-110)
+        }
+    }
+    skinny_epilogue<MT, EPI, R>(p, acc, n0, li, g, rstd);
 }
 
 int g_skinny_nt = 1, g_skinny_nw = 0;
 
 int g_skinny_r = 0;
 int g_prefill_tiled = 1;             // seedmi_set_option("prefill_tiled", 0|1): LDS-tiled prefill attention (0 = first-round kernel)
+int g_ablate_norm = 0;               // seedmi_set_option("decode_ablate_norm", 1): timing only, skips the decode RMSNorm launches
 int g_decode_fused = 1;              // seedmi_set_option("decode_fused", 0|1): RoPE + KV append folded into decode attention
 
 template <int EPI, int NW, bool NT, bool PACKED, int R>
@@ -796,12 +840,17 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
     if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
     if (!strcmp(key, "prefill_tiled") && (value == 0 || value == 1)) { g_prefill_tiled = value; return SEEDMI_OK; }
+    if (!strcmp(key, "decode_ablate_norm") && (value == 0 || value == 1)) { g_ablate_norm = value; return SEEDMI_OK; }
     return SEEDMI_E_SHAPE;
 }
 
 static int skinny_entry(bool packed, int M, int N, int K, const void* A, int lda, const void* W, int ldw,
                         const void* residual, int ldr, int epilogue, void* C, int ldc, int a_packed, int c_packed,
-                        void* stream) {
+                        void* stream, float norm_eps = 0.f, void* xp_out = nullptr) {
+    if (xp_out && (epilogue != EPI_BIAS_RESIDUAL || (N % 32) || (ldc % 4))) {
+        seedmi_set_error("seedmi_gemm_skinny: the fragment-major copy needs the BIAS_RESIDUAL epilogue, N %% 32 == 0 and ldc %% 4 == 0");
+        return SEEDMI_E_SHAPE;
+    }
     if ((a_packed && (K % 32)) || (c_packed && (epilogue != EPI_SWIGLU || (N % 64)))) {
         seedmi_set_error("seedmi_gemm_skinny: packed activations need K %% 32 == 0; packed output is SWIGLU-only with N %% 64 == 0");
         return SEEDMI_E_SHAPE;
@@ -821,6 +870,7 @@ static int skinny_entry(bool packed, int M, int N, int K, const void* A, int lda
     p.R = (const bf16_t*)residual; p.ldr = ldr;
     p.C = (bf16_t*)C; p.ldc = ldc;
     p.a_packed = a_packed; p.c_packed = c_packed;
+    p.norm_eps = norm_eps; p.xp_out = (bf16_t*)xp_out;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case EPI_NONE: return packed ? launch_skinny<EPI_NONE, true>(p, s) : launch_skinny<EPI_NONE, false>(p, s);
@@ -843,6 +893,13 @@ extern "C" int seedmi_gemm_skinny_packed_bf16(int M, int N, int K, const void* A
                                               const void* residual, int ldr, int epilogue, void* C, int ldc, int a_packed,
                                               int c_packed, void* stream) {
     return skinny_entry(true, M, N, K, A, lda, W_packed, 8, residual, ldr, epilogue, C, ldc, a_packed, c_packed, stream);
+}
+
+extern "C" int seedmi_gemm_skinny_norm_bf16(int M, int N, int K, const void* A, int a_packed, const void* W_packed, float rms_eps,
+                                            const void* residual, int ldr, int epilogue, void* C, int ldc, int c_packed,
+                                            void* x_packed_out, void* stream) {
+    return skinny_entry(true, M, N, K, A, K, W_packed, 8, residual, ldr, epilogue, C, ldc, a_packed, c_packed, stream, rms_eps,
+                        x_packed_out);
 }
 
 extern "C" size_t seedmi_pack_skinny_weights_bytes(int N, int K) {
@@ -982,11 +1039,23 @@ extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const vo
     // rmsnorm -> [QKV], attention -> [o_proj], rmsnorm -> [gate|up] -> SwiGLU -> [down]; the residual stream stays row-major
     const bool pk = (T == 1 && M <= 64 && (h % 128) == 0 && (F % 128) == 0 && w->layer[0].qkv_wp && w->layer[0].o_wp &&
                      w->layer[0].gate_up_wp && w->layer[0].down_wp);
+    // folded RMSNorm (w->norm_folded: the fragment-major qkv / gate_up / lm_head copies carry weight * gamma): the GEMM that
+    // consumes a norm computes the row scale itself from the activation fragments it streams, and the GEMM that produces the
+    // residual stream also writes its fragment-major copy - no norm launches, no extra pass over x (64 launches per 8B step)
+    const bool fold = pk && w->norm_folded && !g_ablate_norm;
+    if (fold) CK(seedmi_pack_activations_bf16(t.x, h, t.xn, M, h, stream));
     for (int l = 0; l < w->layers; ++l) {
         const seedmi_llama_layer_t& L = w->layer[l];
-        if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, M, h, stream));
-        else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, h, M, h, stream));
-        CK(linear(M, 3 * h, h, t.xn, h, L.qkv_w, L.qkv_wp, nullptr, 0, EPI_NONE, t.qkv, 3 * h, stream, pk, 0));
+        if (fold) {
+            CK(seedmi_gemm_skinny_norm_bf16(M, 3 * h, h, t.xn, 1, L.qkv_wp, w->rms_eps, nullptr, 0, EPI_NONE, t.qkv, 3 * h, 0, nullptr,
+                                            stream));
+        } else {
+            if (pk && g_ablate_norm) {}                      // timing ablation: stale xn
+            else if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, M, h, stream));
+            else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, h, M, h, stream));
+            CK(linear(M, 3 * h, h, t.xn, h, L.qkv_w, (pk || !w->norm_folded) ? L.qkv_wp : nullptr, nullptr, 0, EPI_NONE, t.qkv, 3 * h,
+                      stream, pk, 0));
+        }
         if (T == 1 && g_decode_fused) {
             // RoPE + cache append + attention in one launch (bit-identical to the two-kernel form below)
             CK(seedmi_llama_decode_attention_bf16(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, L.k_cache,
@@ -998,21 +1067,36 @@ extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const vo
             CK(seedmi_llama_attention_bf16(t.q, h, L.k_cache, L.v_cache, t.att, h, batch, T, H, hd, w->tmax, past_len, scale,
                                            pk, past_len_dev, stream));
         }
-        CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
-        if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, M, h, stream));
-        else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, h, M, h, stream));
-        CK(linear(M, 2 * F, h, t.xn, h, L.gate_up_w, L.gate_up_wp, nullptr, 0, EPI_SWIGLU, t.act, F, stream, pk, pk));
-        CK(linear(M, h, F, t.act, F, L.down_w, L.down_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
+        if (fold) {
+            CK(seedmi_gemm_skinny_norm_bf16(M, h, h, t.att, 1, L.o_wp, 0.f, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, 0, t.xn, stream));
+            CK(seedmi_gemm_skinny_norm_bf16(M, 2 * F, h, t.xn, 1, L.gate_up_wp, w->rms_eps, nullptr, 0, EPI_SWIGLU, t.act, F, 1, nullptr,
+                                            stream));
+            CK(seedmi_gemm_skinny_norm_bf16(M, h, F, t.act, 1, L.down_wp, 0.f, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, 0, t.xn, stream));
+        } else {
+            CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
+            if (pk && g_ablate_norm) {}
+            else if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, M, h, stream));
+            else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, h, M, h, stream));
+            CK(linear(M, 2 * F, h, t.xn, h, L.gate_up_w, (pk || !w->norm_folded) ? L.gate_up_wp : nullptr, nullptr, 0, EPI_SWIGLU, t.act,
+                      F, stream, pk, pk));
+            CK(linear(M, h, F, t.act, F, L.down_w, L.down_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
+        }
     }
     const bool pk_head = (batch <= 64 && (h % 128) == 0 && w->lm_head_p);
     if (last_only) {
         // final norm + lm_head on the last position of every sequence only (decode fast path)
-        if (pk_head) CK(seedmi_rmsnorm_packed_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, batch, h, stream));
-        else CK(seedmi_rmsnorm_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, h, batch, h, stream));
-        CK(linear(batch, w->vocab, h, t.xn, h, w->lm_head, w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream, pk_head, 0));
+        if (pk_head && w->norm_folded && !g_ablate_norm) {
+            if (!fold) CK(seedmi_pack_activations_bf16(t.x + (size_t)(T - 1) * h, T * h, t.xn, batch, h, stream));
+            CK(seedmi_gemm_skinny_norm_bf16(batch, w->vocab, h, t.xn, 1, w->lm_head_p, w->rms_eps, nullptr, 0, EPI_NONE, logits, ldl, 0,
+                                            nullptr, stream));
+        } else {
+            if (pk_head) CK(seedmi_rmsnorm_packed_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, batch, h, stream));
+            else CK(seedmi_rmsnorm_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, h, batch, h, stream));
+            CK(linear(batch, w->vocab, h, t.xn, h, w->lm_head, w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream, pk_head, 0));
+        }
     } else {
         CK(seedmi_rmsnorm_bf16(t.x, h, w->norm_w, w->rms_eps, t.xn, h, M, h, stream));
-        CK(linear(M, w->vocab, h, t.xn, h, w->lm_head, w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream));
+        CK(linear(M, w->vocab, h, t.xn, h, w->lm_head, w->norm_folded ? nullptr : w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream));
     }
     return SEEDMI_OK;
 }

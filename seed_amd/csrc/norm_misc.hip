@@ -270,6 +270,30 @@ extern "C" int seedmi_rmsnorm_packed_bf16(const void* x, int ldx, const void* ga
     return launch_norm<true, true>(x, ldx, gamma, nullptr, eps, out_packed, cols, rows, cols, (hipStream_t)stream);
 }
 
+// rows [rows, cols] (row stride ldx) -> the decode GEMM's fragment-major activation layout, no arithmetic (the folded-RMSNorm
+// decode chain feeds UN-normalised rows to its GEMMs): 16-byte chunk c of row m goes to
+// (((m>>4)*(cols>>5) + (c>>2))*64 + (c&3)*16 + (m&15)) * 8 elements.
+static __global__ void pack_rows_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ out, int rows, int cols) {
+    const int nchunks = cols >> 3;
+    const long long total = (long long)rows * nchunks;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / nchunks), c = (int)(idx - (long long)m * nchunks);
+        const uint4 v = *(const uint4*)(x + (size_t)m * ldx + 8 * c);
+        *(uint4*)(out + ((size_t)((m >> 4) * (cols >> 5) + (c >> 2)) * 64 + (c & 3) * 16 + (m & 15)) * 8) = v;
+    }
+}
+
+extern "C" int seedmi_pack_activations_bf16(const void* x, int ldx, void* out_packed, int rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0 || (cols % 32) || (ldx % 8) || (((uintptr_t)x | (uintptr_t)out_packed) & 15)) {
+        seedmi_set_error("seedmi_pack_activations_bf16: rows=%d cols=%d ldx=%d (cols multiple of 32, 16-byte aligned)", rows, cols, ldx);
+        return SEEDMI_E_SHAPE;
+    }
+    const long long total = (long long)rows * (cols / 8);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (bf16_t*)out_packed, rows, cols);
+    return seedmi_check_launch("pack_activations");
+}
+
 extern "C" int seedmi_im2col_patch(const void* img, int img_is_fp32, void* col, int batch, int chans, int hw, int patch,
                                    int kpad, void* stream) {
     if (batch <= 0 || hw % patch || kpad % 8 || kpad < chans * patch * patch) {

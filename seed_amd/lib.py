@@ -57,7 +57,7 @@ class LlamaWeights(C.Structure):
     _fields_ = ([(n, _i) for n in ("hidden", "layers", "heads", "ffn", "vocab", "vocab_pad", "max_pos", "tmax",
                                    "batch_cap")] + [("rms_eps", C.c_float)] +
                 [("embed", _vp), ("layer", C.POINTER(LlamaLayer)), ("norm_w", _vp), ("lm_head", _vp),
-                 ("cos_t", _vp), ("sin_t", _vp), ("lm_head_p", _vp)])
+                 ("cos_t", _vp), ("sin_t", _vp), ("lm_head_p", _vp), ("norm_folded", _i)])
 
 
 # name -> (restype, argtypes); must list every symbol include/seedmi.h declares (tests check the export table)
@@ -83,6 +83,8 @@ SIGNATURES = {
     "seedmi_gemm_skinny_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "seedmi_pack_skinny_weights_bytes": (C.c_size_t, [_i, _i]),
     "seedmi_pack_skinny_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "seedmi_gemm_skinny_norm_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "seedmi_pack_activations_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "seedmi_gemm_skinny_packed_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "seedmi_rmsnorm_packed_bf16": (_i, [_vp, _i, _vp, C.c_float, _vp, _i, _i, _vp]),
     "seedmi_tokenize_workspace_bytes": (C.c_size_t, [C.POINTER(TokenizerWeights), _i]),

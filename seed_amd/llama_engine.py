@@ -28,7 +28,7 @@ def _round_up(x, m):
 
 class LlamaEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: LlamaConfig, device="cuda", batch_cap: int = 32,
-                 tmax: Optional[int] = None, decode_packed: bool = True):
+                 tmax: Optional[int] = None, decode_packed: bool = True, fold_norm: bool = True):
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -42,6 +42,9 @@ class LlamaEngine:
             L.check(self.lib.seedmi_check_device(), "seedmi_check_device")
         self.batch_cap = batch_cap
         self.decode_packed = decode_packed     # second, fragment-major copy of every weight for the M <= 64 path
+        # the fragment-major qkv / gate_up / lm_head copies carry weight * gamma of the RMSNorm in front of them: decode steps
+        # then need no norm launches (the GEMM derives the row scale from the activations it streams)
+        self.fold_norm = bool(fold_norm and decode_packed)
         self.tmax = tmax or cfg.max_pos
         self.vocab_pad = _round_up(cfg.vocab, 16)
         self._keep = []
@@ -55,10 +58,13 @@ class LlamaEngine:
         self._keep.append(t)
         return t
 
-    def _packed(self, w: torch.Tensor):
-        """Fragment-major copy for the weight-streaming decode GEMM (288 GB of HBM: the 2x copy is cheap)."""
+    def _packed(self, w: torch.Tensor, gamma: Optional[torch.Tensor] = None):
+        """Fragment-major copy for the weight-streaming decode GEMM (288 GB of HBM: the 2x copy is cheap).  With ``gamma``
+        (and fold_norm) the copy holds round_bf16(w * gamma): the RMSNorm weight of the norm feeding this projection."""
         if not self.decode_packed:
             return None
+        if gamma is not None and self.fold_norm:
+            w = (w.float() * gamma.to(self.device).float().unsqueeze(0)).to(torch.bfloat16).contiguous()
         N, K = w.shape
         out = torch.empty(self.lib.seedmi_pack_skinny_weights_bytes(N, K) // 2, dtype=torch.bfloat16, device=self.device)
         with torch.cuda.device(self.device):
@@ -84,13 +90,13 @@ class LlamaEngine:
             qkv = self._dev(torch.cat([sd[pre + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0))
             o = self._dev(sd[pre + "self_attn.o_proj.weight"])
             l.qkv_w, l.o_w = p(qkv), p(o)
-            l.qkv_wp, l.o_wp = p(self._packed(qkv)), p(self._packed(o))
+            l.qkv_wp, l.o_wp = p(self._packed(qkv, sd[pre + "input_layernorm.weight"])), p(self._packed(o))
             l.ln2_w = p(self._dev(sd[pre + "post_attention_layernorm.weight"]))
             gate, up = sd[pre + "mlp.gate_proj.weight"], sd[pre + "mlp.up_proj.weight"]
             gu = self._dev(torch.stack((gate, up), dim=1).reshape(2 * F, h))
             dn = self._dev(sd[pre + "mlp.down_proj.weight"])
             l.gate_up_w, l.down_w = p(gu), p(dn)
-            l.gate_up_wp, l.down_wp = p(self._packed(gu)), p(self._packed(dn))
+            l.gate_up_wp, l.down_wp = p(self._packed(gu, sd[pre + "post_attention_layernorm.weight"])), p(self._packed(dn))
             kc = torch.zeros(self.batch_cap, cfg.heads, self.tmax, cfg.head_dim, dtype=torch.bfloat16, device=self.device)
             vc = torch.zeros_like(kc)
             self.k_cache.append(kc)
@@ -103,7 +109,8 @@ class LlamaEngine:
         lm[:cfg.vocab] = sd["lm_head.weight"].to(torch.bfloat16).cpu()
         lm = self._dev(lm)
         w.lm_head = p(lm)
-        w.lm_head_p = p(self._packed(lm))
+        w.lm_head_p = p(self._packed(lm, sd["model.norm.weight"]))
+        w.norm_folded = 1 if self.fold_norm else 0
         # LlamaRotaryEmbedding.__init__ (llama_xformer.py:118-134)
         hd = cfg.head_dim
         inv_freq = 1.0 / (cfg.rope_base ** (torch.arange(0, hd, 2).float() / hd))

@@ -473,3 +473,64 @@ def test_error_reporting(lib):
     assert rc == -1 and b"multiple of 64" in lib.seedmi_last_error()
     rc = lib.seedmi_attention_bf16(None, 8, None, 8, None, 8, None, 8, 1, 1, 80, 4, 4, 1.0, 0, 1, None)
     assert rc != 0
+
+
+def _unpack_activations(packed, rows, cols):
+    """Inverse of the fragment-major activation layout: element (m, k) lives at
+    (((m>>4)*(cols>>5) + (k>>5))*64 + ((k>>3)&3)*16 + (m&15))*8 + (k&7)."""
+    m = torch.arange(rows).unsqueeze(1)
+    k = torch.arange(cols).unsqueeze(0)
+    idx = (((m >> 4) * (cols >> 5) + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (m & 15)) * 8 + (k & 7)
+    return packed.cpu()[idx]
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(32, 768, 512, "none"), (7, 1536, 1024, "swiglu"), (17, 512, 1408, "residual"),
+                                       (32, 12288, 4096, "none"), (64, 256, 256, "none")])
+def test_skinny_gemm_with_folded_rmsnorm(lib, M, N, K, epi):
+    """seedmi_gemm_skinny_norm_bf16: un-normalised fragment-major rows in, weight * gamma streamed, row scale
+    rsqrt(mean(x^2) + eps) applied to the fp32 accumulators; plus the fragment-major second copy of a residual result and
+    seedmi_pack_activations_bf16 (pure permutation, bit-exact)."""
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    eps = 1e-6
+    x = bf(rand(gen, M, K) * 3.0)
+    gamma = bf(1.0 + 0.1 * rand(gen, K))
+    W = bf(rand(gen, N, K) * 0.05)
+    Wg = bf(W * gamma.unsqueeze(0))
+    xd = x.bfloat16().cuda()
+    rows_p = (M + 15) // 16 * 16
+    xp = torch.zeros(rows_p * K, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.seedmi_pack_activations_bf16(L.ptr(xd), K, L.ptr(xp), M, K, L.stream_ptr()), "pack_activations")
+    torch.cuda.synchronize()
+    assert torch.equal(_unpack_activations(xp, M, K).float(), x)
+    Wd = Wg.bfloat16().cuda()
+    Wp = torch.empty(lib.seedmi_pack_skinny_weights_bytes(N, K) // 2, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.seedmi_pack_skinny_weights(L.ptr(Wd), K, N, K, L.ptr(Wp), L.stream_ptr()), "pack_weights")
+    rstd = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + eps).float()
+    y = (x.double() @ Wg.double().t()).float() * rstd                     # fp32 accumulate, scale, then ONE rounding
+    if epi == "none":
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, L.ptr(xp), 1, L.ptr(Wp), eps, None, 0, L.EPI_NONE, L.ptr(C), N, 0, None,
+                                                 L.stream_ptr()), "skinny_norm")
+        torch.cuda.synchronize()
+        assert_close_bf16(C, r(y), f"skinny+rmsnorm M{M} N{N} K{K}", atol_ulps=1.5, frac=0.998)
+    elif epi == "swiglu":
+        C = torch.zeros(M, N // 2, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, L.ptr(xp), 1, L.ptr(Wp), eps, None, 0, L.EPI_SWIGLU, L.ptr(C), N // 2, 0,
+                                                 None, L.stream_ptr()), "skinny_norm swiglu")
+        torch.cuda.synchronize()
+        yh = r(y)
+        gate, up = yh[:, 0::2], yh[:, 1::2]
+        want = r(r(torch.nn.functional.silu(gate)) * up)
+        assert_close_bf16(C, want, f"skinny+rmsnorm+swiglu M{M}", atol_ulps=2.0, frac=0.995)
+    else:
+        # residual epilogue without the scaling (rms_eps = 0) and with the fragment-major second copy
+        res = bf(rand(gen, M, N))
+        Rd = res.bfloat16().cuda()
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        outp = torch.zeros(rows_p * N, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, L.ptr(xp), 1, L.ptr(Wp), 0.0, L.ptr(Rd), N, L.EPI_BIAS_RESIDUAL, L.ptr(C), N, 0,
+                                                 L.ptr(outp), L.stream_ptr()), "skinny residual + packed copy")
+        torch.cuda.synchronize()
+        want = r(r((x.double() @ Wg.double().t()).float()) + res)
+        assert_close_bf16(C, want, f"skinny residual M{M}", atol_ulps=1.5, frac=0.998)
+        assert torch.equal(_unpack_activations(outp, M, N), C.cpu())     # the second copy is the same bits, permuted
