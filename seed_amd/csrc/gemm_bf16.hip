@@ -1069,6 +1069,13 @@ extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, con
         seedmi_set_error("seedmi_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
         return SEEDMI_E_ALIGN;
     }
+    // operand offsets are 32-bit element indices inside the kernels (LDS-DMA sources): keep every matrix below 2^31 elements
+    const long long lim = 0x7fffffffLL;
+    if ((long long)M * lda > lim || (long long)N * ldw > lim || ((long long)M + (long long)row_extra * (M / (row_group > 0 ? row_group : 1) + 1)) * ldc > lim ||
+        (residual && (long long)M * ldr > lim)) {
+        seedmi_set_error("seedmi_gemm_bf16: a matrix exceeds 2^31 elements (M=%d N=%d K=%d): split the batch", M, N, K);
+        return SEEDMI_E_SHAPE;
+    }
     if ((epilogue == EPI_BIAS_RESIDUAL || epilogue == EPI_PATCH_EMBED) && !residual) {
         seedmi_set_error("seedmi_gemm_bf16: residual epilogue without a residual pointer");
         return SEEDMI_E_SHAPE;

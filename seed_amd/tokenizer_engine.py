@@ -41,6 +41,7 @@ class TokenizerEngine:
         self._keep = []          # tensors owning the device memory referenced by the C structs
         self._ws = None
         self._ws_batch = 0
+        self.max_batch = max(1, min(1024, (2 ** 31 - 1) // (cfg.n_tokens * max(cfg.vit_ffn, 3 * cfg.vit_dim)) - 1))
         self._pack(state_dict)
 
     # ------------------------------------------------------------------ packing
@@ -169,6 +170,10 @@ class TokenizerEngine:
             images = images.float()
         images = images.contiguous()
         B = images.shape[0]
+        if B > self.max_batch and taps is None:
+            # one C call addresses its matrices with 32-bit element offsets (B * n_tokens * ffn < 2^31): larger batches are a
+            # sequence of calls on the same stream (the batch is a pure map over images)
+            return torch.cat([self.encode(images[i:i + self.max_batch]) for i in range(0, B, self.max_batch)], dim=0)
         ids = torch.empty(B, cfg.n_query, dtype=torch.int64, device=self.device)
         ws = self._workspace(B)
         tp = None

@@ -60,6 +60,8 @@ def test_argument_validation_returns_status_codes_and_messages():
     assert "residual" in err()
     assert l.seedmi_gemm_bf16(16, 16, 64, fake, 64, fake, 64, None, None, 0, 99, fake, 16, 0, 0, None) == E_SHAPE
     assert "epilogue" in err()
+    assert l.seedmi_gemm_bf16(600000, 1408, 6144, fake, 6144, fake, 6144, None, None, 0, lib.EPI_BIAS, fake, 1408, 0, 0, None) == E_SHAPE
+    assert "2^31" in err()                       # B > ~1300 images in one call: the host must split the batch
     assert l.seedmi_attention_bf16(fake, 64, fake, 64, fake, 64, fake, 64, 1, 1, 64, 0, 16, 0.125, 0, 1, None) == E_SHAPE
     assert l.seedmi_llama_attention_bf16(fake, 128, fake, fake, fake, 128, 1, 1, 1, 96, 64, 0, 0.1, 0, None, None) == E_SHAPE
     assert "128" in err()
