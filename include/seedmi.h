@@ -44,8 +44,13 @@ int seedmi_version(void);
 const char* seedmi_last_error(void);
 /* 0 if the current device is a gfx950 (MI355X); SEEDMI_E_ARCH otherwise. */
 int seedmi_check_device(void);
-/* Tuning knobs (process wide). "gemm": 0 = automatic kernel choice, 128 / 256 = force that tile kernel;
- * "tokenize_streams": 1 | 2 sub-batches run concurrently inside seedmi_tokenize (default 2 for batch >= 32). */
+/* Tuning / A-B knobs: PROCESS-WIDE state, not thread safe, meant for tests, benchmarks and the tools/ scripts; production callers
+ * leave the defaults.  Keys (value): "gemm" (0 automatic | 128 | 256 | 232 = 32x32x16 MFMA tiles | 255 = one-barrier variant),
+ * "gemm_persist" (0|1), "gemm_group_m" (1..64 m-tiles per L2 tile group), "gemm_min_tiles" (256x256 kernel only at or above this
+ * many tiles), "gemm_ablate" (timing-only ablation masks, results invalid while set), "tokenize_streams" (1..4 concurrent
+ * sub-batches inside seedmi_tokenize, default 2 for batch >= 32), "skinny_nt" / "skinny_waves" / "skinny_rows" (decode GEMM),
+ * "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "decode_ablate_norm" (timing only),
+ * "attn_trv" / "attn_vit" (attention kernel selection).  Unknown keys or values return SEEDMI_E_SHAPE. */
 int seedmi_set_option(const char* key, int value);
 
 /* ---- GEMM epilogues ------------------------------------------------------------------------------------------ */
