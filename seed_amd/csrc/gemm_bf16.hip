@@ -33,7 +33,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A tile + W tile
 int g_gemm_ablate = 0;             // seedmi_set_option("gemm_ablate", mask): timing-only ablations of the 255 kernel
-int g_group_m = 8;                 // seedmi_set_option("gemm_group_m", v): m-tiles per L2 tile group
+int g_group_m = 4;                 // seedmi_set_option("gemm_group_m", v): m-tiles per L2 tile group
 
 struct GemmParams {
     int M, N, K;
