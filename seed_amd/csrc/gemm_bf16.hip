@@ -17,7 +17,7 @@
 // the epilogue issues 16-byte loads/stores only.
 //
 // Workgroups are remapped so that each XCD (private 4 MiB L2) walks a contiguous range of tiles in
-// grouped (8 m-tiles x all n-tiles) order.
+// grouped (4 m-tiles x all n-tiles) order.
 #include <string.h>
 #include <type_traits>
 #include "common.h"
