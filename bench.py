@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
     ap.add_argument("--no-llama", action="store_true", help="skip the SEED-LLaMA-8B decode leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefill14b", action="store_true", help="also run the SEED-LLaMA-14B prefill leg (config 5; ~1 min extra)")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--decode-batch", type=int, default=32)
     ap.add_argument("--decode-new", type=int, default=128)
@@ -151,6 +152,43 @@ def llama_decode_leg(B, n_new):
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_step": bytes_step}}
 
 
+def llama14b_prefill_leg(B=8, T=649):
+    """SURVEY.md section 8d config 5, one GPU's share: SEED-LLaMA-14B (LLaMA-2-13B body), 8 interleaved sequences of 649 tokens
+    (4 x (<img> 32 codes </img>) + 4 x 128 text ids), one prefill forward with the KV cache written; prefill tokens/s and the
+    MFMA fraction of the linear + causal-attention FLOPs."""
+    from seed_amd import config as C
+    from seed_amd.llama_engine import LlamaEngine
+    from seed_amd.weights import make_llama_state_dict
+    cfg = C.LLAMA_14B
+    sd = make_llama_state_dict(cfg, seed=0, device="cuda", dtype=torch.bfloat16)
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=704, decode_packed=False)
+    del sd
+    g = torch.Generator(device="cuda").manual_seed(0)
+    ids = torch.randint(3, 32000, (B, T), device="cuda", generator=g)
+    for r in range(4):
+        s0 = 1 + r * (128 + 34) + 128
+        ids[:, s0] = 32000 + 8192
+        ids[:, s0 + 1:s0 + 33] = 32000 + torch.randint(0, 8192, (B, 32), device="cuda", generator=g)
+        ids[:, s0 + 33] = 32000 + 8193
+    for _ in range(2):
+        eng.reset()
+        eng.forward(ids, last_only=True)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        eng.reset()
+        t0 = time.time()
+        eng.forward(ids, last_only=True)
+        torch.cuda.synchronize()
+        ts.append(time.time() - t0)
+    dt = sorted(ts)[1]
+    flops = B * T * 2.0 * cfg.linear_params() - (B * (T - 1)) * 2.0 * cfg.vocab * cfg.hidden + B * cfg.layers * 2.0 * T * T * cfg.hidden
+    return {"metric": "prefill tokens/s SEED-LLaMA-14B, one GPU's 8 x 649-token share of config 5", "value": round(B * T / dt, 1),
+            "ms": round(dt * 1e3, 2), "batch": B, "seq_len": T,
+            "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,6 +278,12 @@ def main():
                 extra["llama_decode"] = llama_decode_leg(args.decode_batch, args.decode_new)
             except Exception as e:  # the tokenize line must survive a failure of the secondary leg
                 extra["llama_decode"] = {"error": repr(e)[:300]}
+        if world == 1 and args.prefill14b:
+            torch.cuda.empty_cache()
+            try:
+                extra["llama14b_prefill"] = llama14b_prefill_leg()
+            except Exception as e:
+                extra["llama14b_prefill"] = {"error": repr(e)[:300]}
         out["extra"] = extra
         print(json.dumps(out), flush=True)
     if dist is not None:
