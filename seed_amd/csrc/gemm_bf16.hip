@@ -23,6 +23,10 @@
 #include "common.h"
 #include "seedmi_internal.h"
 
+// s_setprio(1) around the MFMA runs of the 256x256 kernel: measured neutral-to-negative (-0.5 % end to end), off by default
+#ifndef SEEDMI_GEMM_PRIO
+#define SEEDMI_GEMM_PRIO 0
+#endif
 #ifndef SEEDMI_GEMM256_DEFAULT
 #define SEEDMI_GEMM256_DEFAULT 1
 #endif
@@ -340,6 +344,7 @@ SEEDMI_DEVINL void gemm_epilogue32(const GemmParams& p, f32x16 (&acc)[4][2], int
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
+    constexpr bool PRIO = SEEDMI_GEMM_PRIO;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
 
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
 
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
 
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
         SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
     }

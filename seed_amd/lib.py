@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseedmi.so")
+LIB_PATH = os.environ.get("SEEDMI_LIB_PATH") or os.path.join(_HERE, "libseedmi.so")     # (override: A/B builds of the library)
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_BIAS_TANH, EPI_SWIGLU, EPI_PATCH_EMBED, EPI_RELU = range(8)
 
