@@ -112,6 +112,14 @@ def cpu_baseline(n_images):
                       f"torch CPU with {cores} of {os.cpu_count()} host threads, {dt:.1f} s"}
 
 
+def _decode_traffic_ratio():
+    try:
+        d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_decode_gemm.json")))
+        return round(d["traffic_bytes"] / d["algorithmic_bytes"], 3)
+    except Exception:
+        return None
+
+
 def llama_decode_leg(B, n_new):
     """SEED-LLaMA-8B (Vicuna-7B body, vocab 40194): image -> 32 tokens -> greedy decode, batch B, bf16."""
     from seed_amd import config as C
@@ -149,7 +157,9 @@ def llama_decode_leg(B, n_new):
     return {"metric": "tokens/s SEED-LLaMA-8B greedy decode", "value": round(tok_s, 1), "batch": B, "new_tokens": n_new,
             "ms_per_step": round(dt / steps * 1e3, 3), "prefill_ms": round(t_prefill * 1e3, 2), "prompt_len": T0,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_step": bytes_step}}
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_step": bytes_step,
+                         # PMC (profiles/r01_pmc_decode_gemm.json): the QKV weight-streaming launch moves 103.7 MB for 101.7 MB
+                         "traffic_over_algorithmic_qkv_gemm": _decode_traffic_ratio()}}
 
 
 def llama14b_prefill_leg(B=8, T=649):
