@@ -274,13 +274,10 @@ def main():
                  # (tools/hbm_read_bench.py); recorded under profiles/, not re-measured here
                  "measured_ceilings": {"mfma_only_loop_tflops": 1980.0, "hbm_stream_read_gbps": 7180.0,
                                        "source": "profiles/r01_gemm_loop_ablation.txt, profiles/r01_hbm_stream_read.json"}}
-        if world == 1:
-            out["roofline"] = qkv_gemm_roofline(B)
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_images)
-        else:
-            out["roofline"] = None
-            out["cpu_baseline"] = None
+        # the dominant kernel is local to a GPU: rank 0 times it at every N (outside the timed region); the CPU baseline
+        # is an N = 1 leg only
+        out["roofline"] = qkv_gemm_roofline(B)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_images) if (world == 1 and not args.no_cpu_baseline) else None
         del eng, images
         torch.cuda.empty_cache()
         if world == 1 and not args.no_llama:
