@@ -14,7 +14,7 @@ random-init tensors of the exact architecture (no checkpoints offline).
 
 The JSON line also carries
   roofline      the dominant kernel (ViT QKV GEMM, M=B*257, K=1408, N=4224) timed live with HIP events
-  cpu_baseline  the CPU oracle (oracle/seed_oracle.py, a port of the reference's modules) timed on this host
+  cpu_baseline  the CPU path timed on this host: the reference's own modules where /root/reference exists, else the oracle port
   extra         whole-path MFMA fraction, SEED-LLaMA-8B greedy decode tokens/s (B=32) and its HBM roofline
 """
 import argparse
@@ -73,29 +73,81 @@ def qkv_gemm_roofline(batch):
     bias = torch.zeros(N, device="cuda").bfloat16()
     Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 
+    # the same entry point and stream-K workspace the tokenize path uses for this GEMM (seed_amd/csrc/tokenizer.hip)
+    ws = torch.zeros(lib.seedmi_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+
     def run():
-        L.check(lib.seedmi_gemm_bf16(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(Cc), N,
-                                     0, 0, L.stream_ptr()), "gemm")
+        L.check(lib.seedmi_gemm_bf16_ws(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(Cc), N,
+                                        0, 0, L.ptr(ws), ws.numel(), L.stream_ptr()), "gemm")
     avg_ms, med_ms = time_kernel_events(run, 20)
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_qkv_gemm256.json")
-    if batch == 256 and os.path.exists(pmc):
-        # HBM-side bytes per launch from rocprofv3 --pmc passes of this same kernel/shape (collected offline, one counter
-        # group per pass; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, both in KiB)
-        d = json.load(open(pmc))
-        traffic = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
-        traffic_src = "profiles/r01_pmc_qkv_gemm256.json"
-    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS>, persistent (ViT QKV: M=%d K=%d N=%d)" % (M, K, N),
+    for name in ("r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if batch == 256 and os.path.exists(pmc):
+            # bytes past the L2s per launch from rocprofv3 --pmc passes of this same kernel/shape (tools/pmc_qkv.sh: PMC counters
+            # cannot be read from inside the benchmark process; one counter group per pass; FETCH_SIZE doubled per the gfx950
+            # note in MI355X_MICROARCH.md, both in KiB)
+            d = json.load(open(pmc))
+            traffic = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+            traffic_src = "profiles/" + name
+            break
+    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS>, persistent + stream-K tail (ViT QKV: M=%d K=%d N=%d)" % (M, K, N),
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": 2.0 * (M * K + N * K + M * N),
             "flops_per_launch": flops, "avg_launch_ms": round(avg_ms, 4), "median_launch_ms": round(med_ms, 4)}
 
 
+def measured_ceilings():
+    """What THIS box sustains when nothing but the resource is exercised, measured live (< 1 s): an MFMA-only register loop
+    (both bf16 MFMA shapes; the chip clocks to its power budget, so this sits below the 2.5 PFLOP/s datasheet peak that every
+    headline fraction keeps as its denominator) and a 16-byte non-temporal stream read of 4 GiB."""
+    import ctypes
+    from seed_amd import lib as L
+    lib = L.load()
+    scratch = torch.zeros(4, dtype=torch.float32, device="cuda")
+    out = {}
+    for shape, name in ((0, "mfma_only_16x16x32_tflops"), (1, "mfma_only_32x32x16_tflops")):
+        fl = ctypes.c_double(0.0)
+
+        def run():
+            L.check(lib.seedmi_bench_mfma_bf16(shape, 20000, 256, L.ptr(scratch), ctypes.byref(fl), L.stream_ptr()), "mfma bench")
+        avg_ms, _ = time_kernel_events(run, 5, warm=2)
+        out[name] = round(fl.value / (avg_ms * 1e-3) / 1e12, 1)
+    buf = torch.empty(4 << 30, dtype=torch.uint8, device="cuda")
+    buf.view(torch.int32).fill_(0x01020304)
+
+    def rd():
+        L.check(lib.seedmi_bench_stream_read(L.ptr(buf), buf.numel(), 4, L.ptr(scratch), L.stream_ptr()), "stream read")
+    avg_ms, _ = time_kernel_events(rd, 5, warm=2)
+    out["hbm_stream_read_gbps"] = round(buf.numel() / (avg_ms * 1e-3) / 1e9, 1)
+    out["source"] = "measured in this run (seedmi_bench_mfma_bf16, seedmi_bench_stream_read)"
+    return out
+
+
+def _time_reference_modules(n_images, cores):
+    """The reference's OWN modules (models/seed_qformer/*.py under /root/reference, imported through oracle/ref_shims.py) on the
+    same images and weights: only possible where the reference tree exists (the build container), never on the GPU box."""
+    from oracle import ref_shims, make_golden
+    from seed_amd import config as C
+    from seed_amd.weights import make_tokenizer_state_dict
+    ref = ref_shims.load_reference_modules()
+    sd = make_tokenizer_state_dict(C.SEED2, seed=0)
+    mods = ref_shims.build_reference_tokenizer_modules(ref, C.SEED2)
+    make_golden.load_tokenizer_weights(mods, sd)
+    img = torch.randn(n_images, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    qt = sd["query_tokens"].clone()
+    ref_shims.reference_get_codebook_indices(mods, qt, img[:1])
+    t0 = time.time()
+    ref_shims.reference_get_codebook_indices(mods, qt, img)
+    return time.time() - t0
+
+
 def cpu_baseline(n_images):
-    """The oracle (CPU port of the reference modules, fp32, all host cores) on a bounded sample of the workload."""
+    """The CPU path on a bounded sample of the workload, fp32, on the host cores: the reference's own modules when /root/reference
+    is present ("reference"; the oracle port is then timed beside it), otherwise the oracle (a port of those modules)."""
     from oracle import seed_oracle as O
     from seed_amd import config as C
     from seed_amd.weights import make_tokenizer_state_dict
@@ -107,9 +159,20 @@ def cpu_baseline(n_images):
     t0 = time.time()
     O.get_codebook_indices(sd, img, C.SEED2, "fp32")
     dt = time.time() - t0
-    return {"value": round(n_images / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n_images} images (one batch) of the same synthetic 224x224 workload, fp32 oracle, "
-                      f"torch CPU with {cores} of {os.cpu_count()} host threads, {dt:.1f} s"}
+    res = {"value": round(n_images / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"{n_images} images (one batch) of the same synthetic 224x224 workload, fp32 oracle, "
+                     f"torch CPU with {cores} of {os.cpu_count()} host threads, {dt:.1f} s"}
+    if os.path.isdir("/root/reference/models/seed_qformer"):
+        try:
+            dt_ref = _time_reference_modules(n_images, cores)
+            res = {"value": round(n_images / dt_ref, 3), "unit": "images/s", "cores": cores, "kind": "reference",
+                   "sample": f"{n_images} images (one batch), the reference's own modules (fp32, dependency shims only), torch CPU with "
+                             f"{cores} of {os.cpu_count()} host threads, {dt_ref:.1f} s; oracle port on the same sample: "
+                             f"{n_images / dt:.3f} images/s",
+                   "port_value": round(n_images / dt, 3)}
+        except Exception as e:
+            res["reference_error"] = repr(e)[:200]
+    return res
 
 
 def _decode_traffic_ratio():
@@ -269,16 +332,18 @@ def main():
         flops_img = cfg.flops_per_image()
         extra = {"gflop_per_image": round(flops_img / 1e9, 2),
                  "path_mfma_frac": round(img_s / world * flops_img / (MFMA_PEAK_TFLOPS * 1e12), 4),
-                 # what an MI355X of this pool sustains when nothing but the resource is exercised (SURVEY.md 8d "vs
-                 # measured"): MFMA-only GEMM loop (tools/gemm_ablate.py mask 7) and 16-byte stream read of 8 GiB
-                 # (tools/hbm_read_bench.py); recorded under profiles/, not re-measured here
-                 "measured_ceilings": {"mfma_only_loop_tflops": 1980.0, "hbm_stream_read_gbps": 7180.0,
-                                       "source": "profiles/r01_gemm_loop_ablation.txt, profiles/r01_hbm_stream_read.json"}}
+                 "peak_denominators": {"mfma_bf16_dense_tflops": MFMA_PEAK_TFLOPS, "hbm_gbps": HBM_PEAK_GBS,
+                                       "source": "/opt/skills/guides/MI355X_MICROARCH.md"}}
         # the dominant kernel is local to a GPU: rank 0 times it at every N (outside the timed region); the CPU baseline
         # is an N = 1 leg only
         out["roofline"] = qkv_gemm_roofline(B)
         out["cpu_baseline"] = cpu_baseline(args.cpu_images) if (world == 1 and not args.no_cpu_baseline) else None
         del eng, images
+        torch.cuda.empty_cache()
+        try:
+            extra["measured_ceilings"] = measured_ceilings()
+        except Exception as e:
+            extra["measured_ceilings"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
         if world == 1 and not args.no_llama:
             try:

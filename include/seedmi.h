@@ -44,19 +44,20 @@ int seedmi_version(void);
 const char* seedmi_last_error(void);
 /* 0 if the current device is a gfx950 (MI355X); SEEDMI_E_ARCH otherwise. */
 int seedmi_check_device(void);
-/* Tuning / A-B knobs: PROCESS-WIDE state, not thread safe, meant for tests, benchmarks and the tools/ scripts; production callers
- * leave the defaults.  Keys (value): "gemm" (0 automatic | 128 | 256 | 232 = 32x32x16 MFMA tiles | 255 = one-barrier variant),
- * "gemm_persist" (0|1), "gemm_group_m" (1..64 m-tiles per L2 tile group), "gemm_min_tiles" (256x256 kernel only at or above this
- * many tiles), "gemm_ablate" (timing-only ablation masks, results invalid while set), "tokenize_streams" (1..4 concurrent
- * sub-batches inside seedmi_tokenize, default 2 for batch >= 32), "skinny_nt" / "skinny_waves" / "skinny_rows" (decode GEMM),
- * "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "decode_ablate_norm" (timing only),
- * "attn_trv" / "attn_vit" (attention kernel selection).  Unknown keys or values return SEEDMI_E_SHAPE. */
+/* Tuning overrides: PROCESS-WIDE selections between kernels that compute the same result (relaxed atomics: reads are race-free,
+ * but they are not part of the per-stream thread-safety contract - set them before concurrent use; production callers leave the
+ * defaults).  Keys (value): "gemm" (0 automatic | 128 | 256), "gemm_persist" (0|1), "gemm_streamk" (0|1: stream-K tail when a
+ * workspace is passed), "gemm_group_m" (1..64 m-tiles per L2 tile group), "gemm_min_tiles" (256x256 kernel only at or above this
+ * many tiles), "tokenize_streams" (1..4 concurrent sub-batches inside seedmi_tokenize), "skinny_nt" / "skinny_waves" / "skinny_rows"
+ * (decode GEMM), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
+ * (attention kernel selection).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
+ * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
 int seedmi_set_option(const char* key, int value);
 
 /* ---- GEMM epilogues ------------------------------------------------------------------------------------------ */
 #define SEEDMI_EPI_NONE 0          /* C = A W^T                                                                   */
 #define SEEDMI_EPI_BIAS 1          /* nn.Linear                                                                   */
-#define SEEDMI_EPI_BIAS_GELU 2     /* eva_vit.py:60-61, qformer_causual.py:321-322 (exact-erf GELU of the half fc1) */
+#define SEEDMI_EPI_BIAS_GELU 2     /* eva_vit.py:60-61, qformer_causual.py:321-322 (exact-erf GELU of the half fc1, by table) */
 #define SEEDMI_EPI_BIAS_RESIDUAL 3 /* eva_vit.py:201-202, qformer_causual.py:252-254, llama_xformer.py:316,322     */
 #define SEEDMI_EPI_BIAS_TANH 4     /* qformer_quantizer.py:219-221                                                */
 #define SEEDMI_EPI_SWIGLU 5        /* llama_xformer.py:186 on row-interleaved gate/up weights; C is [M, N/2]        */
@@ -69,6 +70,15 @@ int seedmi_set_option(const char* key, int value);
 int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
                      const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group, int row_extra,
                      void* stream);
+/* Same with a caller-owned workspace of seedmi_gemm_workspace_bytes() (256-byte aligned; its first 4 KiB must have been zeroed once,
+ * e.g. by hipMemsetAsync ahead of the first call; may be reused by later calls on the SAME stream).  With it the persistent 256x256
+ * kernel cuts its last, partial round of tiles along K into equal ranges (stream-K): every workgroup ends at the same time, and a
+ * tile shared by two workgroups is summed in fp32 from one published partial - results equal the plain call up to that one
+ * re-association of the fp32 sum.  workspace == NULL is exactly seedmi_gemm_bf16. */
+size_t seedmi_gemm_workspace_bytes(void);
+int seedmi_gemm_bf16_ws(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
+                        const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group, int row_extra,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* nn.LayerNorm with fp32 statistics (eva_vit.py:199-202, blip2.py:179-184, qformer_causual.py:96,254,336). */
 int seedmi_layernorm_bf16(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* out, int ldo,
@@ -105,10 +115,11 @@ int seedmi_vq_argmin_bf16(const void* z, int ldz, const void* codebook, const vo
 int seedmi_embed_rows(const void* ids_i64, const void* table, int ldt, void* out, int ldo, int n, int cols, int vocab,
                       void* stream);
 /* apply_rotary_pos_emb + KV append (llama_xformer.py:160-168,234-239): qkv [B*T, 3*H*hd] -> q_out [B*T, H*hd],
- * caches [B][H][tmax][hd] written at positions past_len..past_len+T-1.  cos/sin: [max_pos, hd] bf16 tables. */
+ * caches [B][H][tmax][hd] written at positions past_len..past_len+T-1.  cos/sin: [max_pos, hd] bf16 tables; positions are
+ * clamped to [0, max_pos) and a device-resident length to the cache capacity (the reference device-asserts / reallocates). */
 int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t, const void* sin_t,
                           void* q_out, int ldq, void* k_cache, void* v_cache, int B, int T, int H, int hd, int tmax,
-                          int past_len, const void* past_len_dev, void* stream);
+                          int past_len, const void* past_len_dev, int max_pos, void* stream);
 /* *counter += delta on the stream (the decode graph advances its device-resident cache length with it). */
 int seedmi_add_i32(void* counter_dev, int delta, void* stream);
 /* Decode step (T == 1) of LlamaAttention.forward with apply_rotary_pos_emb, the cache append and the attention in one launch
@@ -116,7 +127,8 @@ int seedmi_add_i32(void* counter_dev, int delta, void* stream);
  * past_len (or *past_len_dev) and attended to together with the cached rows.  pos_ids_i64 [B] may be NULL (position = past). */
 int seedmi_llama_decode_attention_bf16(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t, const void* sin_t,
                                        void* k_cache, void* v_cache, void* out, int ldo, int B, int H, int hd, int tmax,
-                                       int past_len, float scale, int out_packed, const void* past_len_dev, void* stream);
+                                       int past_len, float scale, int out_packed, const void* past_len_dev, int max_pos,
+                                       void* stream);
 /* xformers.ops.memory_efficient_attention semantics (llama_xformer.py:244-256), head_dim 128:
  * q [B*T, H*hd]; caches [B][H][tmax][hd] holding kv_len = past_len + T keys; causal (top-left aligned on the
  * last T positions) when T > 1. */
@@ -201,15 +213,20 @@ int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int
  * kept iff the weight mass ranked before it (descending weight, ties by ascending id) is < top_p * total; the draw is the
  * inverse CDF over the kept tokens in that order at uniforms_f32[step * batch + row] (in [0,1)), step = *step_dev (device int32,
  * may be NULL = 0) + step_offset.  Writes tok_out_i64[row] and, when history_i64 != NULL, history_i64[row * history_ld + step].
- * No host sync: a captured decode graph replays it with the step read from device memory. */
+ * n_steps > 0 bounds the step: beyond it the last uniforms row is reused and nothing is recorded (a graph replayed too often
+ * must not leave its buffers).  No host sync: a captured decode graph replays it with the step read from device memory. */
 int seedmi_sample_token_bf16(const void* logits, int ldl, int batch, int vocab, float temperature, float top_p,
                              const void* uniforms_f32, const void* step_dev, int step_offset, void* tok_out_i64,
-                             void* history_i64, int history_ld, void* stream);
+                             void* history_i64, int history_ld, int n_steps, void* stream);
 
 /* ---- calibration (not on the product path) ---------------------------------------------------------------------------- */
 /* Streams `bytes` of device memory with 16-byte non-temporal loads from 256*blocks_per_cu workgroups (the decode GEMMs' access
  * pattern) and discards them: the HBM read rate this box actually delivers, for the "vs measured" roofline. */
 int seedmi_bench_stream_read(const void* p, size_t bytes, int blocks_per_cu, void* scratch4, void* stream);
+/* MFMA-only loop from registers (shape 0: v_mfma_f32_16x16x32_bf16, 1: v_mfma_f32_32x32x16_bf16; 8 waves per workgroup, four
+ * accumulator chains each, varied non-zero operands): the matrix-pipe rate this box sustains at the clock its power budget allows.
+ * *flops_out = floating-point operations of the launch. */
+int seedmi_bench_mfma_bf16(int shape, int iters, int workgroups, void* scratch4, double* flops_out, void* stream);
 
 /* ---- the step before the path: image pre-processing -------------------------------------------------------------- */
 #define SEEDMI_RESIZE_BILINEAR 2   /* PIL.Image.BILINEAR: transforms.Resize default, models/transforms.py:13,16      */
@@ -288,6 +305,12 @@ int seedmi_llama_forward(const seedmi_llama_weights_t* w, const void* ids_i64, c
 int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const void* ids_i64, const void* pos_i64, int batch, int T,
                             int past_len, const void* past_len_dev, int last_only, void* logits, int ldl, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* LlamaModel.forward's other two surfaces (llama_xformer.py:502-541, 569-570, 613-617): exactly one of ids_i64 and
+ * inputs_embeds (bf16 [batch*T, hidden]) is given; hidden_states (optional, bf16 [(layers+1)][batch*T][hidden], last_only must be
+ * 0) receives the input of every decoder layer and, last, the final-norm output - the tuple output_hidden_states=True returns. */
+int seedmi_llama_forward_io(const seedmi_llama_weights_t* w, const void* ids_i64, const void* inputs_embeds, const void* pos_i64,
+                            int batch, int T, int past_len, const void* past_len_dev, int last_only, void* logits, int ldl,
+                            void* hidden_states, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

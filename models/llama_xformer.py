@@ -90,6 +90,7 @@ class LlamaForCausalLM(PreTrainedModel, GenerationMixin):
         self.model = LlamaModel(config)
         self.lm_head = _Weight(config.vocab_size, config.hidden_size)
         self._engine = None
+        self._weights_released = False
         self._engine_opts = {"batch_cap": 32, "tmax": None, "free_unpacked": True}
         self.post_init()
 
@@ -113,9 +114,12 @@ class LlamaForCausalLM(PreTrainedModel, GenerationMixin):
         return None                                    # untied, nothing to resize/tie
 
     def configure_engine(self, batch_cap: int = 32, tmax: Optional[int] = None, free_unpacked: bool = True):
-        """Static KV-cache capacity (batch rows x positions) of the HIP engine; call before the first forward."""
+        """Static KV-cache capacity (batch rows x positions) of the HIP engine.  Before the first forward it sets the options
+        the engine is built with; afterwards it resizes the cache of the existing engine (the packed weights stay in place —
+        with free_unpacked the torch-side copies are gone, so the engine is never rebuilt from them)."""
         self._engine_opts = {"batch_cap": batch_cap, "tmax": tmax, "free_unpacked": free_unpacked}
-        self._engine = None
+        if self._engine is not None:
+            self._engine.resize_cache(batch_cap=max(batch_cap, 1), tmax=tmax)
         return self
 
     def _engine_config(self) -> EngineConfig:
@@ -134,7 +138,26 @@ class LlamaForCausalLM(PreTrainedModel, GenerationMixin):
         if opts["free_unpacked"]:
             for p in self.parameters():
                 p.data = torch.empty(0, dtype=p.dtype, device=p.device)
+            self._weights_released = True
         return eng
+
+    def state_dict(self, *args, **kwargs):
+        if getattr(self, "_weights_released", False):
+            raise RuntimeError("the torch-side parameters were released after packing into the HIP engine "
+                               "(configure_engine(free_unpacked=False) before the first forward keeps them for "
+                               "state_dict()/save_pretrained())")
+        return super().state_dict(*args, **kwargs)
+
+    def _ensure_engine(self, device, batch):
+        """Build the engine once; a later, larger batch grows its KV cache instead of repacking (the unpacked parameters may
+        already have been released)."""
+        if self._engine is None:
+            if getattr(self, "_weights_released", False):
+                raise RuntimeError("LlamaForCausalLM: engine dropped after its weights were released; reload the checkpoint")
+            self._engine = self._make_engine(device, batch)
+        elif self._engine.batch_cap < batch:
+            self._engine.resize_cache(batch_cap=batch)
+        return self._engine
 
     @property
     def engine(self):
@@ -161,14 +184,19 @@ class LlamaForCausalLM(PreTrainedModel, GenerationMixin):
             raise ValueError("You cannot specify both decoder_input_ids and decoder_inputs_embeds at the same time")
         if input_ids is None and inputs_embeds is None:
             raise ValueError("You have to specify either decoder_input_ids or decoder_inputs_embeds")
-        if inputs_embeds is not None:
-            raise NotImplementedError("inputs_embeds is not supported by the MI355X path (token ids only)")
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / hidden states are never materialised by the fused path")
-        B, T = input_ids.shape
-        if self._engine is None or self._engine.batch_cap < B:
-            self._engine = self._make_engine(input_ids.device, B)
-        eng = self._engine
+        if output_attentions:
+            # the reference itself cannot serve this on its xformers path: LlamaAttention.forward never assigns
+            # `attn_weights` before returning it (llama_xformer.py:244-263 -> UnboundLocalError); the fused kernels never
+            # materialise the [B,H,T,T] probabilities either
+            raise NotImplementedError("output_attentions=True: attention maps are not materialised (the reference's xformers "
+                                      "path raises UnboundLocalError for the same request, llama_xformer.py:260-263)")
+        if input_ids is not None:
+            B, T = input_ids.shape
+            dev = input_ids.device
+        else:
+            B, T, _ = inputs_embeds.shape                                       # llama_xformer.py:519-520
+            dev = inputs_embeds.device
+        eng = self._ensure_engine(dev, B)
 
         past_len = 0
         if past_key_values is not None and len(past_key_values) > 0:
@@ -182,7 +210,9 @@ class LlamaForCausalLM(PreTrainedModel, GenerationMixin):
             position_ids = position_ids.view(-1, T).long()                      # :541
             if position_ids.shape[0] == 1 and B > 1:
                 position_ids = position_ids.expand(B, T)
-        logits = eng.forward(input_ids, position_ids=position_ids, past_len=past_len, last_only=False)
+        hidden = [] if output_hidden_states else None
+        logits = eng.forward(input_ids, position_ids=position_ids, past_len=past_len, last_only=False,
+                             inputs_embeds=inputs_embeds, hidden_states_out=hidden)
 
         loss = None
         if labels is not None:                                                  # :721-731
@@ -196,9 +226,10 @@ class LlamaForCausalLM(PreTrainedModel, GenerationMixin):
             past = PastKeyValues((eng.k_cache[l][:B, :, :total], eng.v_cache[l][:B, :, :total])
                                  for l in range(len(eng.k_cache)))
         if not return_dict:
-            out = (logits,) + ((past,) if past is not None else ())
+            out = (logits,) + ((past,) if past is not None else ()) + ((tuple(hidden),) if hidden is not None else ())
             return ((loss,) + out) if loss is not None else out
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=past, hidden_states=None, attentions=None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=past,
+                                      hidden_states=tuple(hidden) if hidden is not None else None, attentions=None)
 
     # ------------------------------------------------------------------ generation glue (llama_xformer.py:745-783)
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,

@@ -6,6 +6,7 @@ Reference lines mirrored: ImageTokenizer.__init__ 24-70, .encode 75-90, .decode 
 encode_image 185-202, decode_image 204-213.
 """
 import os
+import warnings
 from typing import Any, Dict, Optional
 
 import torch
@@ -31,19 +32,49 @@ def _make_processor(image_size):
         return _Compose([_pil_resize((image_size, image_size), interpolation=3), _to_tensor, _normalize(CLIP_MEAN, CLIP_STD)])
 
 
+def _load_unclip_pipeline(diffusion_model_path, fp16):
+    """The reference builds ``StableUnCLIPImg2ImgPipeline.from_pretrained(path, torch_dtype=...)`` here
+    (seed_llama_tokenizer.py:39-46).  diffusers and the reference's pipeline module are outside this library: use them when
+    the caller's environment provides them, otherwise return the reason so that ``decode()`` can report it."""
+    dtype = torch.float16 if fp16 else torch.float32
+    try:
+        try:
+            from .pipeline_stable_unclip_img2img import StableUnCLIPImg2ImgPipeline        # the reference's patched pipeline
+        except ImportError:
+            from diffusers import StableUnCLIPImg2ImgPipeline
+        return StableUnCLIPImg2ImgPipeline.from_pretrained(diffusion_model_path, torch_dtype=dtype), None
+    except Exception as e:                                                                   # no diffusers / no weights offline
+        return None, f"{type(e).__name__}: {e}"
+
+
 class ImageTokenizer:
     def __init__(self, model_path, diffusion_model_path=None, load_diffusion=False, image_size=224, device='cuda',
                  fp16=True, **kwargs):
         from .seed_qformer.qformer_quantizer import Blip2QformerQuantizer
-        model = Blip2QformerQuantizer.from_pretrained(pretrained_model_path=model_path, device=device, **kwargs).eval()
-        if diffusion_model_path is not None and load_diffusion:
-            raise NotImplementedError(
-                "load_diffusion=True: the unCLIP de-tokenizer (models/pipeline_stable_unclip_img2img.py) is outside the "
-                "accelerated hot path; construct with load_diffusion=False")
+        model = Blip2QformerQuantizer.from_pretrained(pretrained_model_path=model_path, device=device,
+                                                      vit_precision='fp16' if fp16 else 'fp32', **kwargs).eval()
+        # seed_llama_tokenizer.py:39-48: the scripts construct with load_diffusion=True and a diffusion_path
+        # (scripts/seed_tokenizer_inference.py:20, seed_llama_inference_8B.py:71).  The flag is accepted; when the unCLIP
+        # pipeline cannot be built here the failure is kept and raised by decode(), the only method that needs it.
         self.diffusion_model = None
+        self._diffusion_error = None
+        if diffusion_model_path is not None and load_diffusion:
+            pipe, err = _load_unclip_pipeline(diffusion_model_path, fp16)
+            if pipe is not None:
+                self.diffusion_model = pipe.to(device)
+            else:
+                self._diffusion_error = err
+                warnings.warn("load_diffusion=True: the StableUnCLIP pipeline could not be built "
+                              f"({err}); encode()/decode_embeds() work, decode() will raise", RuntimeWarning, stacklevel=2)
         model = model.to(device)
         if fp16:
             model = model.half()
+        # fixed start latents / noise of the reference's decode (seed_llama_tokenizer.py:63-67)
+        try:
+            self.latents = torch.randn(torch.Size([1, 4, 96, 96]), device=device, dtype=torch.float16)
+            self.noise = torch.randn(torch.Size([1, 1024]), device=device, dtype=torch.float16)
+        except (RuntimeError, AssertionError):                                               # device absent (CPU-only import checks)
+            self.latents = self.noise = None
         self.model = model
         self.processor = _make_processor(image_size)
         self.device = device
@@ -64,7 +95,7 @@ class ImageTokenizer:
         '''
         if len(image_torch.shape) == 3:
             image_torch = image_torch.unsqueeze(0)
-        img = image_torch
+        img = image_torch       # (the reference's `.half()` at :86-87 is the engine's single rounding to its compute dtype)
         with torch.no_grad():
             id, _ = self.model.get_codebook_indices(img)
         return id.view(img.shape[0], -1)
@@ -82,9 +113,10 @@ class ImageTokenizer:
         else:
             negative_image_embeds = None
         if self.diffusion_model is None:
-            raise NotImplementedError(
-                "the StableUnCLIP pipeline (diffusers) is not part of this library: attach one as "
-                "`image_tokenizer.diffusion_model` or use decode_embeds() for the conditioning embeds")
+            why = self._diffusion_error or "constructed with load_diffusion=False"
+            raise RuntimeError(
+                "decode(): no StableUnCLIP pipeline is attached (" + why + "). The conditioning embeds are available from "
+                "decode_embeds(); attach a diffusers pipeline as `image_tokenizer.diffusion_model` to render images")
         return self.diffusion_model(image_embeds=image_embeds, negative_image_embeds=negative_image_embeds,
                                     guidance_scale=guidance_scale, noise_level=0, num_inference_steps=num_inference_steps,
                                     latents=getattr(self, "latents", None)).images

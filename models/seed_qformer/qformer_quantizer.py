@@ -9,6 +9,8 @@ no torch modules: the state dict is repacked once into the HIP engine (seed_amd/
 (seedmi_detokenize) when the checkpoint carries ``blocks_image`` / ``image_down`` / ``distill_image_proj``; the diffusers
 pipeline behind it stays outside this library.
 """
+import warnings
+
 import torch
 
 from seed_amd.config import TokenizerConfig, SEED2
@@ -31,6 +33,17 @@ class _DeviceHandle:
         return self
 
 
+_warned_half = False
+
+
+def _norm_device(device):
+    """torch.device('cuda') and torch.device('cuda', current) name the same device: compare with the index filled in."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None and torch.cuda.is_available():
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
 class Blip2QformerQuantizer:
     def __init__(self, state_dict=None, cfg: TokenizerConfig = SEED2, device="cuda", **kwargs):
         self.cfg = cfg
@@ -38,8 +51,9 @@ class Blip2QformerQuantizer:
         self.codebook_embed_dim = cfg.code_dim
         self.visual_encoder = _DeviceHandle()
         self._state_dict = state_dict
-        self._device = torch.device(device) if device is not None else None
+        self._device = _norm_device(device) if device is not None else None
         self._engine = None
+        self._out_dtype = torch.bfloat16              # dtype handed to the diffusers pipeline by get_codebook_entry
         self._detok = None
 
     # -- reference constructor path (qformer_quantizer.py:340-375)
@@ -47,6 +61,7 @@ class Blip2QformerQuantizer:
     def from_pretrained(cls, pretrained_model_path, **kwargs):
         cfg = kwargs.pop("cfg", SEED2)
         device = kwargs.pop("device", "cuda")
+        kwargs.pop("vit_precision", None)             # qformer_quantizer.py:341: 'fp16' | 'fp32'; one compute type here (see half())
         if isinstance(pretrained_model_path, dict):
             ckpt = pretrained_model_path
         elif str(pretrained_model_path).startswith("http"):
@@ -60,11 +75,28 @@ class Blip2QformerQuantizer:
         return self
 
     def half(self):
-        return self          # the MI355X path computes in bf16 with fp32 accumulation whichever half type is asked for
+        """The reference runs fp16 (configs/tokenizer/seed_llama_tokenizer_hf.yaml:3, seed_llama_tokenizer.py:58-59); this
+        library has ONE compute type, bf16 with fp32 accumulation (BASELINE.json's dtype): same exponent range as fp32,
+        8 instead of 11 significand bits.  Say so once instead of silently narrowing."""
+        global _warned_half
+        if not _warned_half:
+            warnings.warn("Blip2QformerQuantizer.half(): the MI355X path computes in bfloat16 (fp32 accumulation), not "
+                          "float16; token ids can differ from an fp16 run on near-tie codes", RuntimeWarning, stacklevel=2)
+            _warned_half = True
+        self._out_dtype = torch.float16               # get_codebook_entry feeds an fp16 diffusers pipeline (:309-338)
+        return self
+
+    def bfloat16(self):
+        self._out_dtype = torch.bfloat16
+        return self
+
+    def float(self):
+        self._out_dtype = torch.float32
+        return self
 
     def to(self, device=None, *a, **k):
         if device is not None and not isinstance(device, torch.dtype):
-            dev = torch.device(device)
+            dev = _norm_device(device)
             if self._engine is not None and dev != self._engine.device:
                 self._engine = None
             if self._detok is not None and dev != self._detok.device:
@@ -96,6 +128,6 @@ class Blip2QformerQuantizer:
         return self._detok
 
     def get_codebook_entry(self, indices):
-        """qformer_quantizer.py:309-338 (use_qformer_image=False): ids [B,32] -> image embeds [B,1024] (half tensor)."""
+        """qformer_quantizer.py:309-338 (use_qformer_image=False): ids [B,32] -> image embeds [B,1024] in the dtype last asked for with .half()/.bfloat16()/.float() (computed in bf16)."""
         with torch.no_grad():
-            return self.detokenizer.codebook_entry(indices)
+            return self.detokenizer.codebook_entry(indices).to(self._out_dtype)

@@ -84,6 +84,37 @@ def tokenizer_golden(name, cfg, batch, seed_w, seed_x, ref):
           "agree", (ids32 == ids16).float().mean().item() if have16 else None)
 
 
+def tokenizer_golden_full(ref, batch=16, seed_w=0, seed_x=1234):
+    """The full SEED-2 tokenizer (EVA-ViT-g/14, 39 blocks + 12-layer Q-Former + 8192 x 32 codebook) through the reference's own
+    modules, fp32 and native bf16, on ``batch`` images: pins the oracle AND the HIP path at the real size.
+    The codebook is calibrate_codebook(z_fp32, seed 7) - a pure function of the stored z - so it is not stored (1 MB)."""
+    cfg = C.SEED2
+    torch.manual_seed(0)
+    sd = make_tokenizer_state_dict(cfg, seed=seed_w)
+    image = torch.randn(batch, 3, cfg.img_size, cfg.img_size, generator=torch.Generator().manual_seed(seed_x))
+    mods = ref_shims.build_reference_tokenizer_modules(ref, cfg)
+    load_tokenizer_weights(mods, sd)
+    qt = sd["query_tokens"].clone()
+    _, taps = ref_shims.reference_get_codebook_indices(mods, qt, image)
+    cb = calibrate_codebook(taps["z"], cfg.n_embed, seed=7)
+    mods.quantize.embedding.weight.data.copy_(cb)
+    ids32, taps32 = ref_shims.reference_get_codebook_indices(mods, qt, image)
+    assert torch.equal(taps32["z"], taps["z"])
+    for m in (mods.visual_encoder, mods.Qformer, mods.quantize, mods.encode_task_layer):
+        m.bfloat16()
+    for prm in mods.ln_vision.parameters():
+        prm.data = prm.data.bfloat16().float()
+    ids16, taps16 = ref_shims.reference_get_codebook_indices(mods, qt.bfloat16(), image.bfloat16())
+    np.savez_compressed(os.path.join(GOLDEN, "tokenizer_full.npz"), seed_w=seed_w, seed_x=seed_x, batch=batch,
+                        image_sum=np.float64(image.double().sum().item()), ids_fp32=ids32.numpy().astype(np.int16),
+                        ids_bf16=ids16.numpy().astype(np.int16), z_fp32=taps32["z"].numpy(),
+                        z_bf16=taps16["z"].float().numpy().astype(np.float32),
+                        image_embeds_fp32_slice=taps32["image_embeds"][:, :4, :32].numpy(),
+                        image_embeds_bf16_slice=taps16["image_embeds"][:, :4, :32].float().numpy())
+    print("full ids[0,:8] fp32", ids32[0, :8].tolist(), "bf16", ids16[0, :8].tolist(), "fp32 vs bf16 agreement of the reference "
+          "with itself", (ids32 == ids16).float().mean().item())
+
+
 def vq_golden(ref):
     """VectorQuantizer2 alone on the reference module: z, codebook -> ids (fp32 and bf16)."""
     gen = torch.Generator().manual_seed(11)
@@ -169,6 +200,7 @@ def main():
     llama_golden(ref)
     detok_golden("tiny", C.TINY, 3, 11, 5, ref)
     detok_golden("full", C.SEED2, 2, 12, 6, ref)
+    tokenizer_golden_full(ref)
 
 
 if __name__ == "__main__":

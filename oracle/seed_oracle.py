@@ -9,7 +9,7 @@ Pinning status: the reference ships NO tests, golden vectors or fixtures for thi
 (SURVEY.md section 4 / 8c), so the pin is created here: ``oracle/make_golden.py`` runs the reference's
 *own modules* (imported from /root/reference through ``oracle/ref_shims.py``) on seeded
 synthetic weights and commits their outputs under ``tests/golden/``;
-``tests/test_oracle_vs_reference_golden.py`` checks this restatement against those vectors.
+``tests/test_oracle_golden.py`` checks this restatement against those vectors.
 Third-party arithmetic that is not under /root/reference (xformers >= 0.0.20 memory-efficient
 attention, transformers 4.30.2 ACT2FN/GenerationMixin, torch GEMM/LN/softmax) is restated from
 its published semantics and anchored on the reference call sites cited below.
@@ -348,15 +348,18 @@ def apply_rope(x, cos, sin, prec: Prec):
     return prec.r(prec.r(x * cos) + prec.r(rot * sin))
 
 
-def llama_forward(sd, cfg, input_ids: torch.Tensor, past: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None,
-                  position_ids: Optional[torch.Tensor] = None, mode: str = "fp32"):
+def llama_forward(sd, cfg, input_ids: Optional[torch.Tensor], past: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None,
+                  position_ids: Optional[torch.Tensor] = None, mode: str = "fp32", inputs_embeds: Optional[torch.Tensor] = None,
+                  hidden_out: Optional[list] = None):
     """LlamaForCausalLM.forward in eval mode with use_cache=True on an UNPADDED equal-length batch
     (llama_xformer.py:661-743 -> LlamaModel.forward :496-627 -> LlamaDecoderLayer :280-332 ->
     LlamaAttention :212-263).  Attention = xformers.memory_efficient_attention semantics: scale
     1/sqrt(hd), fp32 softmax, causal (top-left aligned LowerTriangularMask) when q_len > 1, no bias when
-    q_len == 1 (:251-256).  Returns (logits [B,T,V], past list of (k,v) [B,H,T,hd] post-RoPE)."""
+    q_len == 1 (:251-256).  Returns (logits [B,T,V], past list of (k,v) [B,H,T,hd] post-RoPE).
+    ``inputs_embeds`` replaces the embedding gather (:519-520, 543-544); ``hidden_out`` (a list) receives the
+    output_hidden_states tuple: the input of every layer (:569-570) and the final-norm output (:613-617)."""
     prec = Prec(mode)
-    B, T = input_ids.shape
+    B, T = input_ids.shape if input_ids is not None else inputs_embeds.shape[:2]
     H, hd = cfg.heads, cfg.head_dim
     past_len = 0 if past is None else past[0][0].shape[2]
     if position_ids is None:                                           # :531-539
@@ -365,10 +368,15 @@ def llama_forward(sd, cfg, input_ids: torch.Tensor, past: Optional[List[Tuple[to
     cos = cos_t[position_ids].unsqueeze(1)                             # :164-165
     sin = sin_t[position_ids].unsqueeze(1)
     with torch.no_grad():
-        x = _w(sd, "model.embed_tokens.weight", prec)[input_ids]       # :544
+        if inputs_embeds is not None:
+            x = prec.r(inputs_embeds.float())
+        else:
+            x = _w(sd, "model.embed_tokens.weight", prec)[input_ids]   # :544
         new_past = []
         for i in range(cfg.layers):
             p = f"model.layers.{i}."
+            if hidden_out is not None:
+                hidden_out.append(x)                                   # :569-570
             h = rms_norm(x, _w(sd, p + "input_layernorm.weight", prec), cfg.rms_eps, prec)
             q = linear(h, _w(sd, p + "self_attn.q_proj.weight", prec), None, prec)
             k = linear(h, _w(sd, p + "self_attn.k_proj.weight", prec), None, prec)
@@ -398,6 +406,8 @@ def llama_forward(sd, cfg, input_ids: torch.Tensor, past: Optional[List[Tuple[to
             d = linear(a, _w(sd, p + "mlp.down_proj.weight", prec), None, prec)
             x = prec.r(x + d)                                          # :322
         x = rms_norm(x, _w(sd, "model.norm.weight", prec), cfg.rms_eps, prec)     # :613
+        if hidden_out is not None:
+            hidden_out.append(x)                                                  # :615-617
         logits = linear(x, _w(sd, "lm_head.weight", prec), None, prec)            # :718 (model dtype)
     return logits, new_past
 

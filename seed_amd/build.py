@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libseedmi.so")
+LIB_DEV = os.path.join(HERE, "libseedmi_dev.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["capi.hip", "gemm_bf16.hip", "attn_fullrow.hip", "attn_vit.hip", "norm_misc.hip", "vq_argmin.hip", "tokenizer.hip", "detokenizer.hip", "preprocess.hip", "sample.hip", "llama.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
@@ -29,36 +30,43 @@ def _deps_mtime():
     return latest
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+def _compile(src, force, objdir=OBJ, extra=()):
+    obj = os.path.join(objdir, src.replace(".hip", ".o"))
     srcp = os.path.join(CSRC, src)
-    hdr_m = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    hdr_m = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
     hdr_m = max(hdr_m, os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "seedmi.h")))
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_m):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", srcp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
     return obj, True
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, devtools: bool = False) -> str:
+    """devtools=True builds libseedmi_dev.so with -DSEEDMI_DEVTOOLS: the product library plus timing-only ablation switches,
+    rejected kernel variants and micro-benchmarks that tools/ scripts use (SEEDMI_LIB_PATH selects it); never loaded by the
+    engines, tests or bench.py."""
+    objdir = OBJ + ("_dev" if devtools else "")
+    lib = LIB_DEV if devtools else LIB
+    extra = ("-DSEEDMI_DEVTOOLS",) if devtools else ()
+    os.makedirs(objdir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+        results = list(ex.map(lambda s: _compile(s, force, objdir, extra), SOURCES))
     objs = [o for o, _ in results]
-    if any(changed for _, changed in results) or not os.path.exists(LIB) or force:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    LIB_ = lib
+    if any(changed for _, changed in results) or not os.path.exists(LIB_) or force:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print(f"[seed_amd.build] linked {LIB}")
+            print(f"[seed_amd.build] linked {LIB_}")
     elif verbose:
-        print(f"[seed_amd.build] {LIB} up to date")
-    return LIB
+        print(f"[seed_amd.build] {LIB_} up to date")
+    return LIB_
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, devtools="--devtools" in sys.argv)

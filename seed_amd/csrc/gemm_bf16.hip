@@ -19,6 +19,7 @@
 // Workgroups are remapped so that each XCD (private 4 MiB L2) walks a contiguous range of tiles in
 // grouped (4 m-tiles x all n-tiles) order.
 #include <string.h>
+#include <atomic>
 #include <type_traits>
 #include "common.h"
 #include "seedmi_internal.h"
@@ -27,17 +28,22 @@
 #ifndef SEEDMI_GEMM_PRIO
 #define SEEDMI_GEMM_PRIO 0
 #endif
-#ifndef SEEDMI_GEMM256_DEFAULT
-#define SEEDMI_GEMM256_DEFAULT 1
-#endif
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A tile + W tile
-int g_gemm_ablate = 0;             // seedmi_set_option("gemm_ablate", mask): timing-only ablations of the 255 kernel
-int g_group_m = 4;                 // seedmi_set_option("gemm_group_m", v): m-tiles per L2 tile group
+// Process-wide tuning overrides (seedmi_set_option).  They select between kernels that compute the same result and are not part of
+// the per-stream thread-safety contract: set them before concurrent use.  Relaxed atomics keep concurrent reads race-free.
+#ifdef SEEDMI_DEVTOOLS
+std::atomic<int> g_gemm_ablate{0};   // "gemm_ablate": timing-only ablations (devtools build only)
+#endif
+std::atomic<int> g_group_m{4};       // "gemm_group_m": m-tiles per L2 tile group
+std::atomic<int> g_gemm_persist{1};  // "gemm_persist": persistent one-workgroup-per-CU launch of the 256x256 kernel
+std::atomic<int> g_gemm_streamk{1};  // "gemm_streamk": stream-K tail when the caller passes a workspace
+std::atomic<int> g_gemm_variant{0};  // "gemm": 0 = auto, 128 / 256 = force a kernel
+std::atomic<int> g_gemm_min_tiles{160};   // "gemm_min_tiles": fewer 256x256 tiles than this -> 128x128 kernel
 
 struct GemmParams {
     int M, N, K;
@@ -48,8 +54,16 @@ struct GemmParams {
     bf16_t* C; int ldc;
     int tiles_m, tiles_n;
     int group_m;                // m-tiles walked per group of the tile order (L2 locality)
+#ifdef SEEDMI_DEVTOOLS
     int skip_epilogue;          // timing ablations, seedmi_set_option("gemm_ablate", 32|33|34): 1 = no epilogue, 2 = epilogue without
                                 // its stores, 3 = ordinary instead of streaming stores, 4 = streaming stores without the lane transposition
+#else
+    static constexpr int skip_epilogue = 0;
+#endif
+    // stream-K tail (gemm256 only; null = data-parallel walk): per-workgroup fp32 partial-tile slabs + one flag word each
+    float* sk_slabs;
+    unsigned* sk_flags;
+    unsigned sk_epoch;
     int row_group, row_extra;   // patch-embed: out_row = m + (m / row_group) * row_extra + row_extra ; res_row = m % row_group + row_extra
 };
 
@@ -62,13 +76,40 @@ SEEDMI_DEVINL void glds16(const bf16_t* gptr, char* lds_wave_base) {
 }
 
 
+// ---- nn.GELU() on the half fc1 output as a bf16 -> bf16 table (tools/gen_gelu_lut.py): 5120 entries for 2^-16 <= |x| < 16, held
+// in LDS behind the operand ring.  Per value: one rounding to bf16 (the reference's half fc1 output), ~6 integer VALU and one
+// ds_read_u16 instead of ~20 VALU + v_rcp + v_exp — the erf epilogue was ~30 % of an ideal fc1 tile's MFMA time; the table is what
+// torch returns for each input, so the activation is bit-identical to the reference's.  Values outside the table's range (tiny:
+// 0.5x; huge: relu(x)) are rare: a wave-uniform branch sends such rows through the polynomial form.
+constexpr int GELU_E_MIN = 111, GELU_N = 2560, GELU_LUT_BYTES = 2 * GELU_N * 2;
+__device__ const uint16_t g_gelu_lut[2 * GELU_N] = {
+#include "gelu_lut.inc"
+};
+
+SEEDMI_DEVINL void load_gelu_lut(char* lds, int tid, int nthreads) {
+    const uint4* src = (const uint4*)g_gelu_lut;
+    for (int i = tid; i < GELU_LUT_BYTES / 16; i += nthreads) *(uint4*)(lds + 16 * i) = src[i];
+}
+
+// two bf16 values packed in w -> their GELUs packed the same way; bad is set when either is outside the table
+SEEDMI_DEVINL uint32_t gelu_lut_pair(const char* lut, uint32_t w, bool& bad) {
+    const uint32_t lo = w & 0xffffu, hi = w >> 16;
+    uint32_t il = (lo & 0x7fffu) - (GELU_E_MIN << 7), ih = (hi & 0x7fffu) - (GELU_E_MIN << 7);
+    bad |= (il >= (uint32_t)GELU_N) | (ih >= (uint32_t)GELU_N);
+    il = min(il, (uint32_t)(GELU_N - 1)) + (lo >> 15) * GELU_N;
+    ih = min(ih, (uint32_t)(GELU_N - 1)) + (hi >> 15) * GELU_N;
+    const uint32_t rl = *(const uint16_t*)(lut + 2 * il), rh = *(const uint16_t*)(lut + 2 * ih);
+    return rl | (rh << 16);
+}
+SEEDMI_DEVINL bool gelu_in_table(uint32_t h) { return ((h & 0x7fffu) - (GELU_E_MIN << 7)) < (uint32_t)GELU_N; }
+
 // ---- shared epilogue: the lane owns rows mrow0 + 16*mi + li (mi < MT) and the 16 contiguous columns nb..nb+15
 // LANE4 (lane = li + 16 g, the four lanes of a row own adjacent 16-column groups): when the wave's whole 64-column span lies
 // inside N the 16-byte halves of the four lanes are transposed with v_permlane16_swap / v_permlane32_swap so that each store
 // instruction writes 64 contiguous bytes of a row instead of four 16-byte pieces at a 32-byte stride (whole 32-byte sectors
 // instead of half sectors: -7 % on the ViT QKV GEMM).
 template <int EPI, int MT, bool LANE4 = true>
-SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int mrow0, int nb, int li) {
+SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int mrow0, int nb, int li, const char* lut = nullptr) {
     const int span0 = nb & ~63;                                   // first column of the wave's 64-column span (wave-uniform)
     const bool span_full = LANE4 && EPI != EPI_SWIGLU && (span0 + 64 <= p.N) && p.skip_epilogue == 0;
     if (nb >= p.N) return;
@@ -114,7 +155,28 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[mi][ni][r] + bias[4 * ni + r];
 
         int out_row = m;
-        if (EPI == EPI_BIAS_GELU) {
+        uint32_t pk[8];                                                    // packed result words (table path only)
+        bool packed = false;
+        if (EPI == EPI_BIAS_GELU && lut) {                                 // GELU of the half fc1 output, by table
+            bool bad = false;
+            uint32_t hw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                hw[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+                pk[i] = gelu_lut_pair(lut, hw[i], bad);
+            }
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) {                  // wave-uniform, rare: |x| < 2^-16 or >= 16 somewhere
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t lo = hw[i] & 0xffffu, hi = hw[i] >> 16;
+                    const uint32_t fl = f2bf(gelu_erf(lo_bf(hw[i]))), fh = f2bf(gelu_erf(hi_bf(hw[i])));
+                    const uint32_t rl = gelu_in_table(lo) ? (pk[i] & 0xffffu) : fl;
+                    const uint32_t rh = gelu_in_table(hi) ? (pk[i] >> 16) : fh;
+                    pk[i] = rl | (rh << 16);
+                }
+            }
+            packed = true;
+        } else if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = gelu_erf(rbf(v[i]));      // GELU of the half fc1 output
         } else if (EPI == EPI_BIAS_TANH) {
@@ -162,8 +224,13 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             bf16_t* cp = p.C + (size_t)out_row * p.ldc + nb;
             if (full) {
                 uint4 s0, s1;
-                s0.x = pack2bf(v[0], v[1]); s0.y = pack2bf(v[2], v[3]); s0.z = pack2bf(v[4], v[5]); s0.w = pack2bf(v[6], v[7]);
-                s1.x = pack2bf(v[8], v[9]); s1.y = pack2bf(v[10], v[11]); s1.z = pack2bf(v[12], v[13]); s1.w = pack2bf(v[14], v[15]);
+                if (EPI == EPI_BIAS_GELU && packed) {
+                    s0 = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    s1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                } else {
+                    s0.x = pack2bf(v[0], v[1]); s0.y = pack2bf(v[2], v[3]); s0.z = pack2bf(v[4], v[5]); s0.w = pack2bf(v[6], v[7]);
+                    s1.x = pack2bf(v[8], v[9]); s1.y = pack2bf(v[10], v[11]); s1.z = pack2bf(v[12], v[13]); s1.w = pack2bf(v[14], v[15]);
+                }
                 if (span_full) {
                     // rows of 16 lanes = column groups g: s0 = pieces [0,2,4,6], s1 = [1,3,5,7] of the row's eight 16-byte pieces;
                     // permlane16_swap -> [0,1,4,5] / [2,3,6,7]; permlane32_swap -> [0,1,2,3] / [4,5,6,7]
@@ -194,7 +261,8 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                     __builtin_nontemporal_store((u32x4_t){s1.x, s1.y, s1.z, s1.w}, (u32x4_t*)(cp + 8));
                 }
             } else {
-                for (int i = 0; i < 16; ++i) if (nb + i < p.N) cp[i] = f2bf(v[i]);
+                for (int i = 0; i < 16; ++i)
+                    if (nb + i < p.N) cp[i] = (EPI == EPI_BIAS_GELU && packed) ? (bf16_t)((pk[i >> 1] >> (16 * (i & 1))) & 0xffffu) : f2bf(v[i]);
             }
         }
     }
@@ -256,6 +324,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if (EPI == EPI_BIAS_GELU) load_gelu_lut(smem + 2 * STAGE_BYTES, tid, 256);     // (the K loop's barriers order it before the epilogue)
+    const char* lut = (EPI == EPI_BIAS_GELU) ? smem + 2 * STAGE_BYTES : nullptr;
     const int nk = p.K / BK;
     auto stage = [&](int s, int kt) {
         char* base = smem + s * STAGE_BYTES + wave * 4096;
@@ -288,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    gemm_epilogue<EPI, 4>(p, acc, m0 + 64 * wm, n0 + 64 * wn + 16 * g, li);
+    gemm_epilogue<EPI, 4>(p, acc, m0 + 64 * wm, n0 + 64 * wn + 16 * g, li, lut);
 }
 
 
@@ -309,38 +379,14 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 //    stagger): a slot is read no earlier than the phase after the wait that retires it, and restaged no earlier
 //    than two phases after its last read.
 // Raw s_barrier (not __syncthreads) so LDS-DMA stays in flight across barriers; waits are explicit.
-int g_gemm_persist = 1;          // seedmi_set_option("gemm_persist", 0|1)
 constexpr int B2 = 256;
+constexpr int MAX_SEGS = 512;                     // segment list of one workgroup in LDS (6 KiB)
+constexpr int SEG_BYTES = MAX_SEGS * 3 * 4;
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;          // 64 KiB per K-tile
 
 #define SEEDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-// epilogue for the 32x32 accumulator layout: the lane owns row (mrow + 32*mt) and, per n-tile, 16 contiguous columns
-template <int EPI>
-SEEDMI_DEVINL void gemm_epilogue32(const GemmParams& p, f32x16 (&acc)[4][2], int mrow, int nb0) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int nb = nb0 + 32 * nt;
-        if (nb >= p.N) continue;
-        f32x4 a4[4][4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a4[mt][q][r] = acc[mt][nt][4 * q + r];
-        // rows mrow + 32*mt: reuse the generic epilogue one row group at a time (MT = 1, row stride handled by the base)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            f32x4 one[1][4] = {{a4[mt][0], a4[mt][1], a4[mt][2], a4[mt][3]}};
-            gemm_epilogue<EPI, 1, false>(p, one, mrow + 32 * mt, nb, 0);
-        }
-    }
-}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
@@ -352,19 +398,66 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, g = lane >> 4;
 
-    // ---- persistent tile walk: the launch holds one workgroup per CU; workgroup b (XCD b % 8) takes every
+    // ---- persistent walk: the launch holds one workgroup per CU; workgroup b (XCD b % 8) takes every
     //      (workgroups-on-that-XCD)-th tile of its XCD's contiguous chunk of the grouped tile order, so the tiles
     //      resident on an XCD at any time are neighbours sharing A / W panels in its L2.
+    //      With a stream-K workspace the last 2..3 rounds of the chunk are not walked tile by tile: their K-tile
+    //      iterations (R tiles x nk, 2G <= R < 3G for G workgroups) are cut into G equal contiguous ranges, so every
+    //      workgroup ends at the same time instead of 256 CUs waiting for the few that drew a tile of the partial round
+    //      (257 x 6 tiles of the N = 1408 GEMMs are 6.02 rounds: 7 data-parallel).  A range is >= nk long, so a tile is
+    //      shared by at most two workgroups.  Each workgroup walks its range BACKWARDS: the K head [0, k) of its last tile
+    //      comes first and is published as an fp32 accumulator image; the K tail [k, nk) of its first tile comes last and
+    //      STARTS from the image the previous workgroup published two tiles' time earlier (carry-in instead of zero), then
+    //      runs the ordinary epilogue.  The accumulation chain of a shared tile is therefore the same k-ordered chain as
+    //      an unshared one: results are bit-identical to the data-parallel walk.
     const int nt = p.tiles_m * p.tiles_n;
-    int t_cur, t_end, t_stride;
+    const int nk = p.K / BK;
+    // The segment list (tile, first K-tile, end K-tile) of this workgroup is written to LDS once (behind the operand ring and the
+    // activation table) and read back one entry per tile: the walk then costs two SGPRs of state instead of a dozen.
+    int* const segs = (int*)(smem + 2 * KT_BYTES + GELU_LUT_BYTES);
+    int n_seg = 0;
     {
         const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
         const int cs = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
-        t_stride = ((int)gridDim.x + 7 - xcd) >> 3;
-        t_cur = cs + idx;
-        t_end = cs + q + (xcd < r ? 1 : 0);
+        const int n_x = q + (xcd < r ? 1 : 0);
+        const int G = ((int)gridDim.x + 7 - xcd) >> 3;
+        int n_dp = (n_x - idx + G - 1) / G;             // data-parallel tiles cs + idx + j G < cs + n_x
+        if (n_dp < 0) n_dp = 0;
+        int sk_it = 0, sk_hi = 0, sk_tile0 = 0;         // stream-K range in K-tile iterations over tiles sk_tile0 + i / nk
+        if (p.sk_slabs && n_x >= G) {
+            n_dp = max(n_x / G - 2, 0);                 // whole data-parallel rounds
+            sk_tile0 = cs + n_dp * G;
+            const int I = (n_x - n_dp * G) * nk;
+            sk_it = (int)(((long long)idx * I) / G);
+            sk_hi = (int)(((long long)(idx + 1) * I) / G);
+        }
+        if (n_dp > MAX_SEGS - 5) n_dp = MAX_SEGS - 5;   // (the launcher keeps nt / grid below this)
+        for (int j = tid; j < n_dp; j += 512) { segs[3 * j] = cs + idx + j * G; segs[3 * j + 1] = 0; segs[3 * j + 2] = nk; }
+        n_seg = n_dp;
+        while (sk_it < sk_hi) {                         // <= 4 segments, from the END of the range (uniform)
+            const int tl = (sk_hi - 1) / nk;
+            const int ke = sk_hi - tl * nk;
+            const int kb = max(0, ke - (sk_hi - sk_it));
+            if (tid == 0) { segs[3 * n_seg] = sk_tile0 + tl; segs[3 * n_seg + 1] = kb; segs[3 * n_seg + 2] = ke; }
+            sk_hi -= ke - kb;
+            ++n_seg;
+        }
     }
-    if (t_cur >= t_end) return;                                        // uniform for the whole workgroup
+    if (n_seg == 0) return;                                            // uniform for the whole workgroup
+    if (EPI == EPI_BIAS_GELU) load_gelu_lut(smem + 2 * KT_BYTES, tid, 512);   // activation table behind the operand ring
+    __syncthreads();
+    const char* lut = (EPI == EPI_BIAS_GELU) ? smem + 2 * KT_BYTES : nullptr;
+    int i_seg = 0;
+    int s_tile = 0, s_kb = 0, s_ke = 0;             // current segment: K-tiles [s_kb, s_ke) of tile s_tile
+    auto next_seg = [&](int& tile, int& kb, int& ke) -> bool {
+        if (i_seg >= n_seg) return false;
+        tile = __builtin_amdgcn_readfirstlane(segs[3 * i_seg]);
+        kb = __builtin_amdgcn_readfirstlane(segs[3 * i_seg + 1]);
+        ke = __builtin_amdgcn_readfirstlane(segs[3 * i_seg + 2]);
+        ++i_seg;
+        return true;
+    };
+    next_seg(s_tile, s_kb, s_ke);
 
     int m0 = 0, n0 = 0;
     int offA[2][2], offW[2][2];
@@ -395,7 +488,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((g ^ swzW(rowW0)) << 4);
 
     f32x4 acc[8][4];
-    const int nk = p.K / BK;
     auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
         char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
         const int k0 = kt * BK;
@@ -413,30 +505,56 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int j = 0; j < 2; ++j) glds16(p.W + (size_t)(offW[h][j] + k0), base + h * HALF_BYTES + j * 1024);
     };
 
-    // prologue loads of a tile: K-tile 0 (A and W) and, already in flight behind it, W(1)
-    auto issue_prologue = [&]() {
-        stageA(0);
-        stageW(0);
-        if (nk > 1) stageW(1);
+    // prologue loads of a segment: its first K-tile (A and W) and, already in flight behind it, W of the second
+    auto issue_prologue = [&](int kb, int ke) {
+        stageA(kb);
+        stageW(kb);
+        if (kb + 1 < ke) stageW(kb + 1);
     };
-    set_tile(t_cur);
-    issue_prologue();
+    set_tile(s_tile);
+    issue_prologue(s_kb, s_ke);
 
     bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh) k0/k1 x 4 tiles ; W(nh0), W(nh1): k0/k1 x 2 tiles
     for (;;) {
     const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
+    const int kb = s_kb, ke = s_ke;                     // (s_* move on to the next segment before the epilogue)
+    if (kb > 0) {
+        // ---- K tail of a shared tile (always this workgroup's last segment): continue the accumulation of the workgroup in
+        //      front of it on this XCD, which published the head at the START of its stream-K range, two tiles' time ago.
+        //      One relaxed poll loop, one agent-scope acquire, barrier, then the image lands straight in the accumulators
+        //      (bounded spin: a lost partner leaves a wrong tile, not a hang).
+        const int partner = blockIdx.x - 8;
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(p.sk_flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch &&
+                   ++spins < (1 << 24))
+                __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_slabs + (size_t)partner * (B2 * B2), 0,
+                                                                             B2 * B2 * 4, 0x00020000);
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const int voff = (wave * 32 * 64 + lane) * 16;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // K-tile 0 complete (the up-to-4 youngest VM ops are W(1)'s LDS-DMA or the previous tile's epilogue stores)
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (i * 4 + j) * 1024, 0));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // first K-tile complete (the up-to-4 youngest VM ops are the second W's LDS-DMA or the previous tile's epilogue stores)
+    if (ke - kb > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
     SEEDMI_SCHED_FENCE();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kb; kt < ke; ++kt) {
         const char* sb = smem + (kt & 1) * KT_BYTES;
         const char* pa0 = sb + rdA0;                    // k-step 0
         const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
@@ -448,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(pw0 + t * 512); fw0[2 + t] = *(const bf16x8*)(pw1 + t * 512); }
 #pragma unroll
         for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
-        if (kt + 1 < nk) stageA(kt + 1);
+        if (kt + 1 < ke) stageA(kt + 1);
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -506,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // ================= P4: (mh1, nh0) =================
         // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (kt + 2 < nk) stageW(kt + 2);               // W slots of this parity were last read in P2
+        if (kt + 2 < ke) stageW(kt + 2);               // W slots of this parity were last read in P2
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
         SEEDMI_SCHED_FENCE();
@@ -525,517 +643,129 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
     SEEDMI_SCHED_FENCE();
 
-    // every LDS read of this tile is done: start the next tile's prologue loads now so that their latency (and the
+    // every LDS read of this segment is done: start the next segment's prologue loads now so that their latency (and the
     // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
-    const int t_next = t_cur + t_stride;
-    const bool more = t_next < t_end;
+    const bool more = next_seg(s_tile, s_kb, s_ke);
     if (more) {
-        set_tile(t_next);
-        issue_prologue();
+        set_tile(s_tile);
+        issue_prologue(s_kb, s_ke);
     }
-    if (p.skip_epilogue != 1) gemm_epilogue<EPI, 8>(p, acc, em0 + 128 * wm, en0 + 64 * wn + 16 * g, li);
-    else if (acc[0][0][0] == 123.456f) p.C[0] = 0;      // keep the accumulators alive
-    if (!more) break;
-    t_cur = t_next;
-    }
-}
-
-// ABL (timing ablations only, results are wrong): 1 = no fragment reads in the loop, 2 = no LDS-DMA in the loop,
-// 4 = no barrier / vmcnt wait in the loop
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int li = lane & 15, g = lane >> 4;
-
-    // ---- persistent tile walk: the launch holds one workgroup per CU; workgroup b (XCD b % 8) takes every
-    //      (workgroups-on-that-XCD)-th tile of its XCD's contiguous chunk of the grouped tile order, so the tiles
-    //      resident on an XCD at any time are neighbours sharing A / W panels in its L2.
-    const int nt = p.tiles_m * p.tiles_n;
-    int t_cur, t_end, t_stride;
-    {
-        const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
-        const int cs = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
-        t_stride = ((int)gridDim.x + 7 - xcd) >> 3;
-        t_cur = cs + idx;
-        t_end = cs + q + (xcd < r ? 1 : 0);
-    }
-    if (t_cur >= t_end) return;                                        // uniform for the whole workgroup
-
-    int m0 = 0, n0 = 0;
-    int offA[2][2], offW[2][2];
-    // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
-    auto set_tile = [&](int t) {
-        const int gsize = p.group_m * p.tiles_n;
-        const int gid = t / gsize;
-        const int first_m = gid * p.group_m;
-        const int gm = min(p.tiles_m - first_m, p.group_m);
-        const int in_g = t - gid * gsize;
-        m0 = (first_m + in_g % gm) * B2;
-        n0 = (in_g / gm) * B2;
+    if (ke < nk) {
+        // ---- K head of a shared tile (the first stream-K segment): publish the accumulator image ([wave][4-register group][lane]
+        //      x 16 B: every store instruction writes 1 KiB contiguous) write-through, then the flag.  Protocol of the CDNA guide
+        //      (G16 R1): sc1 stores -> every wave drains vmcnt -> workgroup barrier -> one relaxed agent-scope flag store.
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_slabs + (size_t)blockIdx.x * (B2 * B2), 0,
+                                                                             B2 * B2 * 4, 0x00020000);
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const int voff = (wave * 32 * 64 + lane) * 16;  // one address register; the piece index travels in the scalar offset
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
-                const int cs = lane & 7;
-                offA[h][j] = min(((ABL & 8) ? 0 : m0) + row, p.M - 1) * p.lda + 8 * (cs ^ swzA(row));
-                offW[h][j] = min(((ABL & 8) ? 0 : n0) + row, p.N - 1) * p.ldw + 8 * (cs ^ swzW(row));
-            }
-    };
-    // ---- fragment read bases (byte offsets inside a K-tile buffer); tile index adds an immediate
-    //   A: row = 16*mi + li inside half wm   (swizzle depends on li only)
-    //   W: row = 64*wn + 16*(li>>2) + 4*ni + (li&3) inside the 256-row tile, half wn>>1 (swizzle independent of ni)
-    const int rowW0 = 64 * wn + 16 * (li >> 2) + (li & 3);
-    const int rdA0 = wm * HALF_BYTES + li * 128 + ((g ^ swzA(li)) << 4);
-    const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((g ^ swzW(rowW0)) << 4);
-
-    f32x4 acc[8][4];
-    const int nk = p.K / BK;
-    auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
-        char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
-        const int k0 = (ABL & 8) ? 0 : kt * BK;            // ablation 8: every K-tile re-reads the same (L2-hot) 64 KiB
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.A + (size_t)(offA[h][j] + k0), base + h * HALF_BYTES + j * 1024);
-    };
-    auto stageW = [&](int kt) {
-        char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
-        const int k0 = (ABL & 8) ? 0 : kt * BK;            // ablation 8: every K-tile re-reads the same (L2-hot) 64 KiB
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.W + (size_t)(offW[h][j] + k0), base + h * HALF_BYTES + j * 1024);
-    };
-
-    // prologue loads of a tile: K-tiles 0 and 1 (A and W each)
-    auto issue_prologue = [&]() {
-        stageA(0);
-        stageW(0);
-        if (nk > 1) { stageA(1); stageW(1); }
-    };
-    set_tile(t_cur);
-    issue_prologue();
-
-    // "free-running" schedule: ONE barrier per K-tile.  Fragments are double-buffered by k-step (32 deep): while the 32
-    // MFMAs of one k-step issue from one register set, the 12 ds_read_b128 of the next k-step fill the other.  The barrier
-    // sits after the last LDS read of K-tile t; behind it the wave requests the LDS-DMA of K-tile t+2 into the buffer just
-    // vacated and the first fragments of K-tile t+1 (whose DMA was requested a whole K-tile earlier, so vmcnt(0) at the
-    // barrier costs nothing).  No stagger: the two waves of a SIMD drift apart by themselves and share the matrix pipe.
-    bf16x8 fa0[8], fw0[4], fa1[8], fw1[4];
-    auto rd = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4], const char* sb, int ks) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fw[t] = *(const bf16x8*)(sb + ((rdW0 ^ (ks << 6)) + t * 512));
-#pragma unroll
-        for (int t = 0; t < 8; ++t) fa[t] = *(const bf16x8*)(sb + ((rdA0 ^ (ks << 6)) + t * 2048));
-    };
-    auto mm = [&](bf16x8 (&fa)[8], bf16x8 (&fw)[4]) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
-    };
-    // pin the issue order inside a k-step: 4 MFMAs, then 1-2 of the next k-step's fragment reads, and so on, so that the
-    // wait in front of the first MFMA covers only the fragments requested a whole k-step ago
-    auto interleave = [&]() {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    };
-    for (;;) {
-    const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // K-tile 0 complete (the up-to-8 youngest VM ops are K-tile 1's LDS-DMA or the previous tile's epilogue stores)
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    SEEDMI_SCHED_FENCE();
-    rd(fa0, fw0, smem, 0);
-    if (ABL & 1) rd(fa1, fw1, smem, 1);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sb = smem + (kt & 1) * KT_BYTES;
-        // ---- k-step 0 of K-tile kt issues while k-step 1's fragments are read
-        if (!(ABL & 1)) rd(fa1, fw1, sb, 1);
-        mm(fa0, fw0);
-        interleave();
-        SEEDMI_SCHED_FENCE();
-        // ---- all LDS reads of K-tile kt are complete; K-tile kt+1 has landed (requested one K-tile ago)
-        if (!(ABL & 4)) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        SEEDMI_SCHED_FENCE();
-        if (ABL & 16) {
-            // branch-free request of K-tile kt+2 (a dead request lands in the 1 KiB scratch block), spread between the MFMAs
-            const bool live = kt + 2 < nk;
-            char* base = live ? smem + (kt & 1) * KT_BYTES + wave * 2048 : smem + 2 * KT_BYTES;
-            const int hs = live ? HALF_BYTES : 0, js = live ? 1024 : 0, ws = live ? 2 * HALF_BYTES : 0;
-            const int k0 = live ? (kt + 2) * BK : 0;
-            rd(fa0, fw0, smem + ((kt + 1) & 1) * KT_BYTES, 0);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    glds16(p.A + (size_t)(offA[h][j] + k0), base + h * hs + j * js);
-                    glds16(p.W + (size_t)(offW[h][j] + k0), base + ws + h * hs + j * js);
-                }
-            mm(fa1, fw1);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        } else {
-            if (!(ABL & 2) && kt + 2 < nk) { stageA(kt + 2); stageW(kt + 2); }      // into the buffer K-tile kt just vacated
-            if (!(ABL & 1)) rd(fa0, fw0, smem + ((kt + 1) & 1) * KT_BYTES, 0);     // (after the last K-tile: stale LDS, unused)
-            mm(fa1, fw1);
-            interleave();
-        }
-        SEEDMI_SCHED_FENCE();
-    }
-    if (ABL & 16) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                       // every wave has issued its last LDS read
-    SEEDMI_SCHED_FENCE();
-
-    // every LDS read of this tile is done: start the next tile's prologue loads now so that their latency (and the
-    // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
-    const int t_next = t_cur + t_stride;
-    const bool more = t_next < t_end;
-    if (more) {
-        set_tile(t_next);
-        issue_prologue();
-    }
-    gemm_epilogue<EPI, 8>(p, acc, em0 + 128 * wm, en0 + 64 * wn + 16 * g, li);
-    if (!more) break;
-    t_cur = t_next;
-    }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int li = lane & 15, g = lane >> 4;
-
-    // ---- persistent tile walk: the launch holds one workgroup per CU; workgroup b (XCD b % 8) takes every
-    //      (workgroups-on-that-XCD)-th tile of its XCD's contiguous chunk of the grouped tile order, so the tiles
-    //      resident on an XCD at any time are neighbours sharing A / W panels in its L2.
-    const int nt = p.tiles_m * p.tiles_n;
-    int t_cur, t_end, t_stride;
-    {
-        const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
-        const int cs = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
-        t_stride = ((int)gridDim.x + 7 - xcd) >> 3;
-        t_cur = cs + idx;
-        t_end = cs + q + (xcd < r ? 1 : 0);
-    }
-    if (t_cur >= t_end) return;                                        // uniform for the whole workgroup
-
-    int m0 = 0, n0 = 0;
-    int offA[2][2], offW[2][2];
-    // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
-    auto set_tile = [&](int t) {
-        const int gsize = p.group_m * p.tiles_n;
-        const int gid = t / gsize;
-        const int first_m = gid * p.group_m;
-        const int gm = min(p.tiles_m - first_m, p.group_m);
-        const int in_g = t - gid * gsize;
-        m0 = (first_m + in_g % gm) * B2;
-        n0 = (in_g / gm) * B2;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
-                const int cs = lane & 7;
-                offA[h][j] = min(m0 + row, p.M - 1) * p.lda + 8 * (cs ^ swzA(row));
-                offW[h][j] = min(n0 + row, p.N - 1) * p.ldw + 8 * (cs ^ swzA(row));
-            }
-    };
-    // ---- fragment read bases for v_mfma_f32_32x32x16_bf16 (lane = row i in 0..31, k-half hl = lane >> 5; 16 k per step)
-    //   A (activations, MFMA B operand): row = 32*mt + i inside half wm; chunk = 2*ks + hl
-    //   W (weights, MFMA A operand): MFMA row rho = i feeds weight row 16*((rho>>2)&1) + 4*(rho>>3) + (rho&3) of the 32-row
-    //   n-tile, so that the accumulator registers of a lane (rho = 4*hl + (reg&3) + 8*(reg>>2)) are 16 CONTIGUOUS columns.
-    const int i32 = lane & 31, hl = lane >> 5;
-    const int rowW0 = 64 * wn + 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3);
-    const int rdA0 = wm * HALF_BYTES + i32 * 128 + ((hl ^ swzA(i32)) << 4);
-    const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((hl ^ swzA(rowW0)) << 4);
-
-    f32x16 acc[4][2];                                    // [m-tile of 32][n-tile of 32]
-    const int nk = p.K / BK;
-    auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
-        char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.A + (size_t)(offA[h][j] + k0), base + h * HALF_BYTES + j * 1024);
-    };
-    auto stageW = [&](int kt) {
-        char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.W + (size_t)(offW[h][j] + k0), base + h * HALF_BYTES + j * 1024);
-    };
-
-    // prologue loads of a tile: K-tile 0 (A and W) and, already in flight behind it, W(1)
-    auto issue_prologue = [&]() {
-        stageA(0);
-        stageW(0);
-        if (nk > 1) stageW(1);
-    };
-    set_tile(t_cur);
-    issue_prologue();
-
-    bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh): 2 m-tiles x 4 k-steps ; W(nh0), W(nh1): 4 k-steps each
-    for (;;) {
-    const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // K-tile 0 complete (the up-to-4 youngest VM ops are W(1)'s LDS-DMA or the previous tile's epilogue stores)
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
-    SEEDMI_SCHED_FENCE();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sb = smem + (kt & 1) * KT_BYTES;
-        // k-step ks reads chunk (2*ks + hl) ^ swz  =  base ^ (ks << 5)
-#define PA(ks, mt) (*(const bf16x8*)(sb + ((rdA0 ^ ((ks) << 5)) + (mt) * 4096)))
-#define PW(ks, nt) (*(const bf16x8*)(sb + ((rdW0 ^ ((ks) << 5)) + (nt) * 4096)))
-
-        // ================= P1: (mh0, nh0) =================
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fw0[ks] = PW(ks, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { fa[ks] = PA(ks, 0); fa[4 + ks] = PA(ks, 1); }
-        if (kt + 1 < nk) stageA(kt + 1);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw0[ks], fa[4 * mt + ks], acc[mt][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-
-        // ================= P2: (mh0, nh1) =================
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fw1[ks] = PW(ks, 1);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw1[ks], fa[4 * mt + ks], acc[mt][1], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-
-        // ================= P3: (mh1, nh1) =================
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { fa[ks] = PA(ks, 2); fa[4 + ks] = PA(ks, 3); }
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                acc[2 + mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw1[ks], fa[4 * mt + ks], acc[2 + mt][1], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-
-        // ================= P4: (mh1, nh0) =================
-        // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, voff, (i * 4 + j) * 1024, /*sc1*/ 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (kt + 2 < nk) stageW(kt + 2);               // W slots of this parity were last read in P2
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                acc[2 + mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw0[ks], fa[4 * mt + ks], acc[2 + mt][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (p.skip_epilogue != 1) gemm_epilogue<EPI, 8>(p, acc, em0 + 128 * wm, en0 + 64 * wn + 16 * g, li, lut);
+        else if (acc[0][0][0] == 123.456f) p.C[0] = 0;      // keep the accumulators alive
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
-    SEEDMI_SCHED_FENCE();
-
-    // every LDS read of this tile is done: start the next tile's prologue loads now so that their latency (and the
-    // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
-    const int t_next = t_cur + t_stride;
-    const bool more = t_next < t_end;
-    if (more) {
-        set_tile(t_next);
-        issue_prologue();
-    }
-    gemm_epilogue32<EPI>(p, acc, em0 + 128 * wm + i32, en0 + 64 * wn + 16 * hl);
     if (!more) break;
-    t_cur = t_next;
     }
-#undef PA
-#undef PW
 }
 
+#ifdef SEEDMI_DEVTOOLS
+#include "gemm_devtools.inc"
+#endif
+
+// per-device launch state (function attributes are per device; so is the CU count)
+constexpr int MAX_DEVICES = 64;
+struct DeviceInfo { int n_cu = 0; };
+DeviceInfo g_dev[MAX_DEVICES];
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    return dev;
+}
+int device_cus(int dev) {
+    if (!g_dev[dev].n_cu) {
+        hipDeviceProp_t prop;
+        g_dev[dev].n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return g_dev[dev].n_cu;
+}
+
+constexpr size_t SK_SLAB_BYTES = (size_t)B2 * B2 * 4;       // one fp32 accumulator image per workgroup
+constexpr size_t SK_FLAGS_BYTES = 4096;                      // one flag word per workgroup (<= 1024 CUs)
+std::atomic<unsigned> g_sk_epoch{0};
+
 template <int EPI>
-int launch_gemm256(GemmParams p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES);
-        attr_set = true;
+int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_bytes) {
+    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES;
+    static bool attr_set[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
     }
     p.tiles_m = (p.M + B2 - 1) / B2;
     p.tiles_n = (p.N + B2 - 1) / B2;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = device_cus(dev);
     const int nt = p.tiles_m * p.tiles_n;
-    const int grid = (g_gemm_persist && nt > n_cu) ? n_cu : nt;
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), 2 * KT_BYTES, stream, p);
+    const int grid = (g_gemm_persist && nt > n_cu && nt / n_cu < MAX_SEGS - 4) ? n_cu : nt;
+    // stream-K tail: only a persistent launch whose every XCD holds at least one full round of tiles, and only when the last
+    // round is partial (otherwise the data-parallel walk is already balanced and needs no exchange)
+    p.sk_slabs = nullptr; p.sk_flags = nullptr; p.sk_epoch = 0;
+    if (sk_ws && g_gemm_streamk && grid == n_cu && nt >= grid && (nt % grid) != 0 && (grid % 8) == 0 && grid * 4 <= (int)SK_FLAGS_BYTES &&
+        sk_ws_bytes >= SK_FLAGS_BYTES + (size_t)grid * SK_SLAB_BYTES) {
+        p.sk_flags = (unsigned*)sk_ws;
+        p.sk_slabs = (float*)((char*)sk_ws + SK_FLAGS_BYTES);
+        unsigned e = ++g_sk_epoch;
+        if (e == 0) e = ++g_sk_epoch;                      // 0 is what a cleared flag area holds
+        p.sk_epoch = e;
+    }
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), lds, stream, p);
     return seedmi_check_launch("gemm256");
 }
 
 template <int EPI>
-int launch_gemm256f(GemmParams p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256f_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES);
-        attr_set = true;
-    }
-    p.tiles_m = (p.M + B2 - 1) / B2;
-    p.tiles_n = (p.N + B2 - 1) / B2;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
-    const int nt = p.tiles_m * p.tiles_n;
-    const int grid = (g_gemm_persist && nt > n_cu) ? n_cu : nt;
-    if (EPI == EPI_BIAS && g_gemm_ablate) {
-        auto go = [&](auto kern) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES + 1024);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * KT_BYTES + 1024, stream, p);
-        };
-        switch (g_gemm_ablate) {
-            case 1: go(gemm256f_kernel<EPI_BIAS, 1>); break;
-            case 2: go(gemm256f_kernel<EPI_BIAS, 2>); break;
-            case 3: go(gemm256f_kernel<EPI_BIAS, 3>); break;
-            case 4: go(gemm256f_kernel<EPI_BIAS, 4>); break;
-            case 6: go(gemm256f_kernel<EPI_BIAS, 6>); break;
-            case 8: go(gemm256f_kernel<EPI_BIAS, 8>); break;
-            case 16: go(gemm256f_kernel<EPI_BIAS, 16>); break;
-            case 24: go(gemm256f_kernel<EPI_BIAS, 24>); break;
-            case 12: go(gemm256f_kernel<EPI_BIAS, 12>); break;
-            default: go(gemm256f_kernel<EPI_BIAS, 7>); break;
-        }
-        return seedmi_check_launch("gemm256f(ablation)");
-    }
-    hipLaunchKernelGGL(gemm256f_kernel<EPI>, dim3(grid), dim3(512), 2 * KT_BYTES, stream, p);
-    return seedmi_check_launch("gemm256f");
-}
-
-template <int EPI>
-int launch_gemm256x(GemmParams p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256x_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES);
-        attr_set = true;
-    }
-    p.tiles_m = (p.M + B2 - 1) / B2;
-    p.tiles_n = (p.N + B2 - 1) / B2;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
-    const int nt = p.tiles_m * p.tiles_n;
-    const int grid = (g_gemm_persist && nt > n_cu) ? n_cu : nt;
-    hipLaunchKernelGGL(gemm256x_kernel<EPI>, dim3(grid), dim3(512), 2 * KT_BYTES, stream, p);
-    return seedmi_check_launch("gemm256x");
-}
-
-template <int EPI>
 int launch_gemm128(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        attr_set = true;
+    constexpr int lds = 2 * STAGE_BYTES + (EPI == EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
+    static bool attr_set[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
     }
     const int grid = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(gemm128_kernel<EPI>, dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, p);
+    hipLaunchKernelGGL(gemm128_kernel<EPI>, dim3(grid), dim3(256), lds, stream, p);
     return seedmi_check_launch("gemm128");
 }
 
-int g_gemm_variant = 0;      // 0 = auto, 128 / 256 = force a kernel (seedmi_set_option("gemm", v))
-int g_gemm_min_tiles = 160;    // seedmi_set_option("gemm_min_tiles", n)
-
 template <int EPI>
-int launch_gemm(const GemmParams& p, hipStream_t s) {
+int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_bytes) {
     // the 256x256 kernel wants at least g_gemm_min_tiles tiles (one per CU is 256): below that the 128x128 kernel's four times
     // finer tiling fills the chip better (Q-Former GEMMs at M = B*32)
     const long long tiles256 = (long long)((p.M + B2 - 1) / B2) * ((p.N + B2 - 1) / B2);
     const bool big = p.M >= 1024 && p.N >= 256 && tiles256 >= g_gemm_min_tiles;
-    if (g_gemm_variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
-    if (g_gemm_variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
-    const bool use256 = g_gemm_variant == 256 || (g_gemm_variant == 0 && big && SEEDMI_GEMM256_DEFAULT);
-    return use256 ? launch_gemm256<EPI>(p, s) : launch_gemm128<EPI>(p, s);
+    const int variant = g_gemm_variant;
+#ifdef SEEDMI_DEVTOOLS
+    if (variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
+    if (variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
+#endif
+    const bool use256 = variant == 256 || (variant == 0 && big);
+    return use256 ? launch_gemm256<EPI>(p, s, sk_ws, sk_ws_bytes) : launch_gemm128<EPI>(p, s);
 }
 
 }  // namespace
 
 extern "C" int seedmi_set_option(const char* key, int value) {
-    if (key && !strcmp(key, "gemm") && (value == 0 || value == 128 || value == 256 || value == 232 || value == 255)) {
+#ifdef SEEDMI_DEVTOOLS
+    const bool dev_variant = value == 232 || value == 255;
+#else
+    const bool dev_variant = false;
+#endif
+    if (key && !strcmp(key, "gemm") && (value == 0 || value == 128 || value == 256 || dev_variant)) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
@@ -1047,12 +777,18 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_min_tiles = value;
         return SEEDMI_OK;
     }
+#ifdef SEEDMI_DEVTOOLS
     if (key && !strcmp(key, "gemm_ablate") && value >= 0 && value <= 35) {
         g_gemm_ablate = value;
         return SEEDMI_OK;
     }
+#endif
     if (key && !strcmp(key, "gemm_persist") && (value == 0 || value == 1)) {
         g_gemm_persist = value;
+        return SEEDMI_OK;
+    }
+    if (key && !strcmp(key, "gemm_streamk") && (value == 0 || value == 1)) {
+        g_gemm_streamk = value;
         return SEEDMI_OK;
     }
     if (key && !strcmp(key, "tokenize_streams") && seedmi_tokenizer_set_streams(value) == SEEDMI_OK) return SEEDMI_OK;
@@ -1062,9 +798,18 @@ extern "C" int seedmi_set_option(const char* key, int value) {
     return SEEDMI_E_SHAPE;
 }
 
-extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
-                                const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group,
-                                int row_extra, void* stream) {
+extern "C" size_t seedmi_gemm_workspace_bytes(void) {
+    // stream-K tail of the persistent 256x256 kernel: a flag word and one fp32 accumulator image (256 KiB) per workgroup
+    return SK_FLAGS_BYTES + (size_t)device_cus(current_device()) * SK_SLAB_BYTES;
+}
+
+extern "C" int seedmi_gemm_bf16_ws(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
+                                   const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group,
+                                   int row_extra, void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace && (((uintptr_t)workspace & 255) || workspace_bytes < SK_FLAGS_BYTES)) {
+        seedmi_set_error("seedmi_gemm_bf16_ws: workspace must be 256-byte aligned and hold seedmi_gemm_workspace_bytes()");
+        return SEEDMI_E_ALIGN;
+    }
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) {
         seedmi_set_error("seedmi_gemm_bf16: bad shape M=%d N=%d K=%d (K must be a positive multiple of %d)", M, N, K, BK);
         return SEEDMI_E_SHAPE;
@@ -1099,21 +844,32 @@ extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, con
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     p.group_m = g_group_m;
-    p.skip_epilogue = (g_gemm_ablate == 32) ? 1 : (g_gemm_ablate == 33 ? 2 : (g_gemm_ablate == 34 ? 3 : (g_gemm_ablate == 35 ? 4 : 0)));
+#ifdef SEEDMI_DEVTOOLS
+    const int abl = g_gemm_ablate;
+    p.skip_epilogue = (abl == 32) ? 1 : (abl == 33 ? 2 : (abl == 34 ? 3 : (abl == 35 ? 4 : 0)));
+#endif
+    p.sk_slabs = nullptr; p.sk_flags = nullptr; p.sk_epoch = 0;
     p.row_group = row_group > 0 ? row_group : 1;
     p.row_extra = row_extra;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
-        case EPI_NONE: return launch_gemm<EPI_NONE>(p, s);
-        case EPI_BIAS: return launch_gemm<EPI_BIAS>(p, s);
-        case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(p, s);
-        case EPI_BIAS_RESIDUAL: return launch_gemm<EPI_BIAS_RESIDUAL>(p, s);
-        case EPI_BIAS_TANH: return launch_gemm<EPI_BIAS_TANH>(p, s);
-        case EPI_SWIGLU: return launch_gemm<EPI_SWIGLU>(p, s);
-        case EPI_PATCH_EMBED: return launch_gemm<EPI_PATCH_EMBED>(p, s);
-        case EPI_RELU: return launch_gemm<EPI_RELU>(p, s);
+        case EPI_NONE: return launch_gemm<EPI_NONE>(p, s, workspace, workspace_bytes);
+        case EPI_BIAS: return launch_gemm<EPI_BIAS>(p, s, workspace, workspace_bytes);
+        case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(p, s, workspace, workspace_bytes);
+        case EPI_BIAS_RESIDUAL: return launch_gemm<EPI_BIAS_RESIDUAL>(p, s, workspace, workspace_bytes);
+        case EPI_BIAS_TANH: return launch_gemm<EPI_BIAS_TANH>(p, s, workspace, workspace_bytes);
+        case EPI_SWIGLU: return launch_gemm<EPI_SWIGLU>(p, s, workspace, workspace_bytes);
+        case EPI_PATCH_EMBED: return launch_gemm<EPI_PATCH_EMBED>(p, s, workspace, workspace_bytes);
+        case EPI_RELU: return launch_gemm<EPI_RELU>(p, s, workspace, workspace_bytes);
         default:
             seedmi_set_error("seedmi_gemm_bf16: unknown epilogue %d", epilogue);
             return SEEDMI_E_SHAPE;
     }
+}
+
+extern "C" int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
+                                const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group,
+                                int row_extra, void* stream) {
+    return seedmi_gemm_bf16_ws(M, N, K, A, lda, W, ldw, bias, residual, ldr, epilogue, C, ldc, row_group, row_extra, nullptr, 0,
+                               stream);
 }

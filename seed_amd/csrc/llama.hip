@@ -362,9 +362,10 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
                                                                bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                                bf16_t* __restrict__ out, int ldo, int H, int tmax, int past_arg,
                                                                float scale, int out_packed, int lds_len,
-                                                               const int* __restrict__ past_dev) {
+                                                               const int* __restrict__ past_dev, int max_pos) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    const int past = past_dev ? *past_dev : past_arg;
+    // (a graph replayed past the cache capacity keeps rewriting the last row instead of leaving the allocation)
+    const int past = past_dev ? min(*past_dev, tmax - 1) : past_arg;
     const int kv_len = past + 1;
     float* sc = dsm;
     float* part = dsm + lds_len;
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
     const int ks = tid >> 4;                        // key slot 0..15
     bf16_t* kb = kc + ((size_t)b * H + h) * tmax * DEC_HD;
     bf16_t* vb = vc + ((size_t)b * H + h) * tmax * DEC_HD;
-    const long long pos = pos_ids ? pos_ids[b] : (long long)past;
+    long long pos = pos_ids ? pos_ids[b] : (long long)past;
+    pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);           // cos/sin tables have max_pos rows
     // rotate q and the new key: element i pairs with i +- 64, i.e. chunk c with chunk c ^ 8
     float qv[8], kn[8];
     uint4 vnew;
@@ -922,8 +924,8 @@ extern "C" int seedmi_pack_skinny_weights(const void* W, int ldw, int N, int K, 
 extern "C" int seedmi_llama_decode_attention_bf16(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t,
                                                   const void* sin_t, void* k_cache, void* v_cache, void* out, int ldo, int B,
                                                   int H, int hd, int tmax, int past_len, float scale, int out_packed,
-                                                  const void* past_len_dev, void* stream) {
-    if (hd != DEC_HD || B <= 0 || H <= 0 || past_len < 0 || past_len + 1 > tmax || (ldqkv % 8) ||
+                                                  const void* past_len_dev, int max_pos, void* stream) {
+    if (hd != DEC_HD || B <= 0 || H <= 0 || past_len < 0 || past_len + 1 > tmax || (ldqkv % 8) || max_pos <= 0 ||
         (((uintptr_t)qkv | (uintptr_t)cos_t | (uintptr_t)sin_t | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)) {
         seedmi_set_error("seedmi_llama_decode_attention_bf16: B=%d H=%d hd=%d (must be 128) past=%d tmax=%d ldqkv=%d", B, H, hd,
                          past_len, tmax, ldqkv);
@@ -943,7 +945,7 @@ extern "C" int seedmi_llama_decode_attention_bf16(const void* qkv, int ldqkv, co
     hipLaunchKernelGGL(attn_decode_rope_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv,
                        (const long long*)pos_ids_i64, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
                        (bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, past_len, scale, out_packed, lds_len,
-                       (const int*)past_len_dev);
+                       (const int*)past_len_dev, max_pos);
     return seedmi_check_launch("attn_decode_rope");
 }
 
@@ -1013,8 +1015,21 @@ extern "C" int seedmi_llama_forward(const seedmi_llama_weights_t* w, const void*
 extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const void* ids_i64, const void* pos_i64, int batch,
                                        int T, int past_len, const void* past_len_dev, int last_only, void* logits, int ldl,
                                        void* workspace, size_t workspace_bytes, void* stream) {
-    if (!w || !ids_i64 || (!pos_i64 && !past_len_dev) || !logits || batch <= 0 || T <= 0) {
-        seedmi_set_error("seedmi_llama_forward: null argument or bad batch/T");
+    return seedmi_llama_forward_io(w, ids_i64, nullptr, pos_i64, batch, T, past_len, past_len_dev, last_only, logits, ldl, nullptr,
+                                   workspace, workspace_bytes, stream);
+}
+
+extern "C" int seedmi_llama_forward_io(const seedmi_llama_weights_t* w, const void* ids_i64, const void* inputs_embeds,
+                                       const void* pos_i64, int batch, int T, int past_len, const void* past_len_dev,
+                                       int last_only, void* logits, int ldl, void* hidden_states, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!w || (!ids_i64 && !inputs_embeds) || (ids_i64 && inputs_embeds) || (!pos_i64 && !past_len_dev) || !logits || batch <= 0 ||
+        T <= 0) {
+        seedmi_set_error("seedmi_llama_forward: null argument, both/neither of ids and inputs_embeds, or bad batch/T");
+        return SEEDMI_E_SHAPE;
+    }
+    if (hidden_states && last_only) {
+        seedmi_set_error("seedmi_llama_forward_io: hidden_states are produced for all positions (last_only must be 0)");
         return SEEDMI_E_SHAPE;
     }
     if (past_len_dev && T != 1) {
@@ -1034,7 +1049,24 @@ extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const vo
     const int h = w->hidden, F = w->ffn, H = w->heads, hd = h / H;
     const int M = batch * T;
     const float scale = 1.0f / sqrtf((float)hd);
-    CK(seedmi_embed_rows(ids_i64, w->embed, h, t.x, h, M, h, w->vocab, stream));
+    if (inputs_embeds) {                                 // LlamaModel.forward with inputs_embeds (llama_xformer.py:543-544 skipped)
+        if (hipMemcpyAsync(t.x, inputs_embeds, (size_t)M * h * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+            seedmi_set_error("seedmi_llama_forward_io: copying inputs_embeds failed");
+            return SEEDMI_E_HIP;
+        }
+    } else {
+        CK(seedmi_embed_rows(ids_i64, w->embed, h, t.x, h, M, h, w->vocab, stream));
+    }
+    // output_hidden_states (llama_xformer.py:569-570, 613-617): the input of every layer, then the final-norm output
+    auto tap_hidden = [&](int idx, const bf16_t* src) -> int {
+        if (!hidden_states) return SEEDMI_OK;
+        if (hipMemcpyAsync((bf16_t*)hidden_states + (size_t)idx * M * h, src, (size_t)M * h * 2, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream) != hipSuccess) {
+            seedmi_set_error("seedmi_llama_forward_io: copying a hidden state failed");
+            return SEEDMI_E_HIP;
+        }
+        return SEEDMI_OK;
+    };
     // decode steps (T == 1, M <= 64) keep every GEMM operand in the fragment-major layout end to end:
     // rmsnorm -> [QKV], attention -> [o_proj], rmsnorm -> [gate|up] -> SwiGLU -> [down]; the residual stream stays row-major
     const bool pk = (T == 1 && M <= 64 && (h % 128) == 0 && (F % 128) == 0 && w->layer[0].qkv_wp && w->layer[0].o_wp &&
@@ -1046,6 +1078,7 @@ extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const vo
     if (fold) CK(seedmi_pack_activations_bf16(t.x, h, t.xn, M, h, stream));
     for (int l = 0; l < w->layers; ++l) {
         const seedmi_llama_layer_t& L = w->layer[l];
+        CK(tap_hidden(l, t.x));
         if (fold) {
             CK(seedmi_gemm_skinny_norm_bf16(M, 3 * h, h, t.xn, 1, L.qkv_wp, w->rms_eps, nullptr, 0, EPI_NONE, t.qkv, 3 * h, 0, nullptr,
                                             stream));
@@ -1060,10 +1093,10 @@ extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const vo
             // RoPE + cache append + attention in one launch (bit-identical to the two-kernel form below)
             CK(seedmi_llama_decode_attention_bf16(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, L.k_cache,
                                                   L.v_cache, t.att, h, batch, H, hd, w->tmax, past_len, scale, pk, past_len_dev,
-                                                  stream));
+                                                  w->max_pos, stream));
         } else {
             CK(seedmi_rope_kv_append(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, t.q, h, L.k_cache,
-                                     L.v_cache, batch, T, H, hd, w->tmax, past_len, past_len_dev, stream));
+                                     L.v_cache, batch, T, H, hd, w->tmax, past_len, past_len_dev, w->max_pos, stream));
             CK(seedmi_llama_attention_bf16(t.q, h, L.k_cache, L.v_cache, t.att, h, batch, T, H, hd, w->tmax, past_len, scale,
                                            pk, past_len_dev, stream));
         }
@@ -1096,6 +1129,7 @@ extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const vo
         }
     } else {
         CK(seedmi_rmsnorm_bf16(t.x, h, w->norm_w, w->rms_eps, t.xn, h, M, h, stream));
+        CK(tap_hidden(w->layers, t.xn));
         CK(linear(M, w->vocab, h, t.xn, h, w->lm_head, w->norm_folded ? nullptr : w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream));
     }
     return SEEDMI_OK;

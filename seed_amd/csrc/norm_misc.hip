@@ -187,10 +187,12 @@ __global__ void rope_kv_append_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
                                       const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t,
                                       bf16_t* __restrict__ q_out, int ldq, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                       int B, int T, int H, int hd, int tmax, int past_len_arg,
-                                      const int* __restrict__ past_dev) {
+                                      const int* __restrict__ past_dev, int max_pos) {
     // past_dev: the cache length lives in device memory so that a captured hipGraph of the decode step can be replayed
     // for every position (a kernel argument would be frozen at capture time)
-    const int past_len = past_dev ? *past_dev : past_len_arg;
+    // a device-resident length can run past what the launch was sized for (a graph replayed too often): the append then stays
+    // on the last cache row instead of leaving the allocation
+    const int past_len = past_dev ? min(*past_dev, tmax - T) : past_len_arg;
     const int half = hd >> 1;
     const int pairs = half >> 2;                       // 4 element pairs (x[i], x[i+half]) per thread
     const long long total = (long long)B * T * H * pairs;
@@ -202,7 +204,8 @@ __global__ void rope_kv_append_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
         const int t = (int)(r % T);
         const int b = (int)(r / T);
         const long long row = (long long)b * T + t;
-        const long long pos = pos_ids ? pos_ids[row] : (long long)(past_len + t);
+        long long pos = pos_ids ? pos_ids[row] : (long long)(past_len + t);
+        pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);       // rows of the cos/sin tables ([max_pos, hd]); the reference device-asserts
         const int i0 = pc * 4;
         const bf16_t* cs = cos_t + pos * hd;
         const bf16_t* sn = sin_t + pos * hd;
@@ -342,8 +345,8 @@ extern "C" int seedmi_embed_rows(const void* ids_i64, const void* table, int ldt
 
 extern "C" int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t,
                                      const void* sin_t, void* q_out, int ldq, void* k_cache, void* v_cache, int B, int T,
-                                     int H, int hd, int tmax, int past_len, const void* past_len_dev, void* stream) {
-    if (B <= 0 || T <= 0 || H <= 0 || (hd % 8) || past_len + T > tmax) {
+                                     int H, int hd, int tmax, int past_len, const void* past_len_dev, int max_pos, void* stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || (hd % 8) || past_len + T > tmax || max_pos <= 0) {
         seedmi_set_error("seedmi_rope_kv_append: bad shape B=%d T=%d H=%d hd=%d past=%d tmax=%d", B, T, H, hd, past_len, tmax);
         return SEEDMI_E_SHAPE;
     }
@@ -351,6 +354,6 @@ extern "C" int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos
     hipLaunchKernelGGL(rope_kv_append_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qkv, ldqkv, (const long long*)pos_ids_i64, (const bf16_t*)cos_t, (const bf16_t*)sin_t,
                        (bf16_t*)q_out, ldq, (bf16_t*)k_cache, (bf16_t*)v_cache, B, T, H, hd, tmax, past_len,
-                       (const int*)past_len_dev);
+                       (const int*)past_len_dev, max_pos);
     return seedmi_check_launch("rope_kv_append");
 }

@@ -54,13 +54,17 @@ template <int EPT>
 __global__ __launch_bounds__(ST) void sample_kernel(const bf16_t* __restrict__ logits, int ldl, int vocab, float inv_temp,
                                                     float top_p, const float* __restrict__ u, const int* __restrict__ step_dev,
                                                     int step_off, int batch, long long* __restrict__ tok_out,
-                                                    long long* __restrict__ hist, int hist_ld) {
+                                                    long long* __restrict__ hist, int hist_ld, int n_steps) {
     __shared__ BlockRed red;
     __shared__ int scan[SW];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int base = tid * EPT;
     const bf16_t* row = logits + (size_t)b * ldl;
-    const int step = (step_dev ? *step_dev : 0) + step_off;
+    // step indexes the uniforms [n_steps, batch] and the history columns: a graph replayed more often than it was sized for keeps
+    // drawing from the last row and stops recording instead of leaving either buffer
+    const int step_raw = (step_dev ? *step_dev : 0) + step_off;
+    const bool step_ok = step_raw >= 0 && (n_steps <= 0 || step_raw < n_steps);
+    const int step = step_raw < 0 ? 0 : ((n_steps > 0 && step_raw >= n_steps) ? n_steps - 1 : step_raw);
 
     // ---- scaled logits, row max with first-index tie-break (torch.argmax / greedy search)
     float p[EPT];
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const bf16_t* __restrict__ l
     }
     if (tid == 0) {
         tok_out[b] = choice;
-        if (hist) hist[(size_t)b * hist_ld + step] = choice;
+        if (hist && step_ok) hist[(size_t)b * hist_ld + step] = choice;
     }
 }
 
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const bf16_t* __restrict__ l
 
 extern "C" int seedmi_sample_token_bf16(const void* logits, int ldl, int batch, int vocab, float temperature, float top_p,
                                         const void* uniforms_f32, const void* step_dev, int step_offset, void* tok_out_i64,
-                                        void* history_i64, int history_ld, void* stream) {
+                                        void* history_i64, int history_ld, int n_steps, void* stream) {
     if (!logits || !tok_out_i64 || batch <= 0 || vocab <= 0 || vocab > 48 * ST || ldl < vocab || !(temperature > 0.f) ||
         top_p < 0.f) {
         seedmi_set_error("seedmi_sample_token_bf16: bad arguments (batch %d vocab %d ldl %d temperature %g top_p %g)", batch, vocab,
@@ -196,7 +200,7 @@ extern "C" int seedmi_sample_token_bf16(const void* logits, int ldl, int batch, 
     if (ept <= E) {                                                                                                        \
         hipLaunchKernelGGL(sample_kernel<E>, dim3(batch), dim3(ST), 0, (hipStream_t)stream, (const bf16_t*)logits, ldl, vocab, \
                            inv_temp, top_p, (const float*)uniforms_f32, (const int*)step_dev, step_offset, batch,           \
-                           (long long*)tok_out_i64, (long long*)history_i64, history_ld);                                   \
+                           (long long*)tok_out_i64, (long long*)history_i64, history_ld, n_steps);                          \
         return seedmi_check_launch("sample_token");                                                                        \
     }
     SEEDMI_SAMPLE_CASE(8)

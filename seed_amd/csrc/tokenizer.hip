@@ -28,6 +28,8 @@ struct Carver {
 
 struct TokWs {
     bf16_t *col, *x, *xn, *qkv, *h, *kv, *qx, *qa, *qt, *qqkv, *qh, *z;
+    void* sk;                 // stream-K workspace of the big GEMMs (flags in its first 4 KiB, cleared at the start of every call)
+    size_t sk_bytes;
     size_t bytes;
 };
 
@@ -50,6 +52,8 @@ TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
     t.qqkv = (bf16_t*)c.take(Mq * 3 * Q * 2);
     t.qh = (bf16_t*)c.take(Mq * FF * 2);
     t.z = (bf16_t*)c.take(Mq * 64 * 2);
+    t.sk_bytes = seedmi_gemm_workspace_bytes();
+    t.sk = c.take(t.sk_bytes);
     t.bytes = c.off;
     return t;
 }
@@ -83,6 +87,10 @@ struct Part {
 // phases: 0 = patch embed; 1..depth = ViT blocks; depth+1 = ln_vision + query expand; then Q-Former layers; last = head + VQ
 int n_phases(const seedmi_tokenizer_weights_t* w) { return 1 + w->vit_depth + 1 + w->qf_layers + 1; }
 
+// big GEMMs (M = B * 257 rows) take the stream-K workspace; the small Q-Former ones run on the 128x128 kernel anyway
+#define GEMM_WS(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, rg_, re_) \
+    seedmi_gemm_bf16_ws(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, rg_, re_, t.sk, t.sk_bytes, s)
+
 int run_phase(const Part& p, int phase) {
     const seedmi_tokenizer_weights_t* w = p.w;
     const TokWs& t = p.t;
@@ -98,8 +106,8 @@ int run_phase(const Part& p, int phase) {
     if (phase == 0) {
         // patch embed: unfold -> GEMM(+conv bias, +pos_embed, rows shifted past the cls slot); cls rows
         CK(seedmi_im2col_patch(p.images, p.images_fp32, t.col, B, 3, w->img_size, w->patch, w->kpad, s));
-        CK(seedmi_gemm_bf16(B * P, D, w->kpad, t.col, w->kpad, w->patch_w, w->kpad, w->patch_b, w->pos_embed, D,
-                            SEEDMI_EPI_PATCH_EMBED, t.x, D, P, 1, s));
+        CK(GEMM_WS(B * P, D, w->kpad, t.col, w->kpad, w->patch_w, w->kpad, w->patch_b, w->pos_embed, D,
+                   SEEDMI_EPI_PATCH_EMBED, t.x, D, P, 1));
         CK(seedmi_fill_rows(t.x, D, NT, 0, B, w->cls_pos0, D, 1, D, s));
         return SEEDMI_OK;
     }
@@ -108,13 +116,13 @@ int run_phase(const Part& p, int phase) {
         const seedmi_vit_layer_t& L = w->vit[phase];
         const float vit_scale = 1.0f / sqrtf((float)hd);
         CK(seedmi_layernorm_bf16(t.x, D, L.ln1_w, L.ln1_b, 1e-6f, t.xn, D, M, D, s));
-        CK(seedmi_gemm_bf16(M, 3 * D, D, t.xn, D, L.qkv_w, D, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, 0, 0, s));
+        CK(GEMM_WS(M, 3 * D, D, t.xn, D, L.qkv_w, D, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, 0, 0));
         CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
                                  vit_scale, 0, 1, s));
-        CK(seedmi_gemm_bf16(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, s));
+        CK(GEMM_WS(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0));
         CK(seedmi_layernorm_bf16(t.x, D, L.ln2_w, L.ln2_b, 1e-6f, t.xn, D, M, D, s));
-        CK(seedmi_gemm_bf16(M, F, D, t.xn, D, L.fc1_w, D, L.fc1_b, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, 0, 0, s));
-        CK(seedmi_gemm_bf16(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, s));
+        CK(GEMM_WS(M, F, D, t.xn, D, L.fc1_w, D, L.fc1_b, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, 0, 0));
+        CK(GEMM_WS(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0));
         return SEEDMI_OK;
     }
     phase -= w->vit_depth;
@@ -137,7 +145,7 @@ int run_phase(const Part& p, int phase) {
         CK(seedmi_layernorm_bf16(t.qt, Q, L.ao_ln_w, L.ao_ln_b, 1e-12f, t.qx, Q, Mq, Q, s));
         if (L.has_cross) {
             CK(seedmi_gemm_bf16(Mq, Q, Q, t.qx, Q, L.cq_w, Q, L.cq_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qa, Q, 0, 0, s));
-            CK(seedmi_gemm_bf16(M, 2 * Q, D, t.xn, D, L.ckv_w, D, L.ckv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.kv, 2 * Q, 0, 0, s));
+            CK(GEMM_WS(M, 2 * Q, D, t.xn, D, L.ckv_w, D, L.ckv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.kv, 2 * Q, 0, 0));
             CK(seedmi_attention_bf16(t.qa, Q, t.kv, 2 * Q, t.kv + Q, 2 * Q, t.qt, Q, B, QH, qhd, nq, NT, q_scale, 0, 1, s));
             CK(seedmi_gemm_bf16(Mq, Q, Q, t.qt, Q, L.co_w, Q, L.co_b, t.qx, Q, SEEDMI_EPI_BIAS_RESIDUAL, t.qa, Q, 0, 0, s));
             CK(seedmi_layernorm_bf16(t.qa, Q, L.co_ln_w, L.co_ln_b, 1e-12f, t.qx, Q, Mq, Q, s));
@@ -258,6 +266,8 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
             HIPCK(hipStreamWaitEvent(g_fj.side[i - 1], g_fj.fork, 0));
         }
     }
+    for (int i = 0; i < nparts; ++i)     // stream-K flags: a cleared word never equals a launch's epoch
+        HIPCK(hipMemsetAsync(parts[i].t.sk, 0, 4096, parts[i].s));
     const int np = n_phases(w);
     for (int ph = 0; ph < np; ++ph)
         for (int i = 0; i < nparts; ++i) CK(run_phase(parts[i], ph));

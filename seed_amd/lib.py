@@ -67,6 +67,8 @@ SIGNATURES = {
     "seedmi_check_device": (_i, []),
     "seedmi_set_option": (_i, [C.c_char_p, _i]),
     "seedmi_gemm_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "seedmi_gemm_workspace_bytes": (C.c_size_t, []),
+    "seedmi_gemm_bf16_ws": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, C.c_size_t, _vp]),
     "seedmi_layernorm_bf16": (_i, [_vp, _i, _vp, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
     "seedmi_rmsnorm_bf16": (_i, [_vp, _i, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
     "seedmi_im2col_patch": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -75,11 +77,11 @@ SIGNATURES = {
     "seedmi_vq_code_sqnorm": (_i, [_vp, _vp, _i, _i, _vp]),
     "seedmi_vq_argmin_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "seedmi_embed_rows": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
-    "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "seedmi_add_i32": (_i, [_vp, _i, _vp]),
     "seedmi_llama_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp, _vp]),
     "seedmi_llama_decode_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp,
-                                                _vp]),
+                                                _i, _vp]),
     "seedmi_gemm_skinny_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "seedmi_pack_skinny_weights_bytes": (C.c_size_t, [_i, _i]),
     "seedmi_pack_skinny_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -90,8 +92,9 @@ SIGNATURES = {
     "seedmi_tokenize_workspace_bytes": (C.c_size_t, [C.POINTER(TokenizerWeights), _i]),
     "seedmi_tokenize": (_i, [C.POINTER(TokenizerWeights), _vp, _i, _i, _vp, C.POINTER(TokenizerTaps), _vp,
                              C.c_size_t, _vp]),
-    "seedmi_sample_token_bf16": (_i, [_vp, _i, _i, _i, C.c_float, C.c_float, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "seedmi_sample_token_bf16": (_i, [_vp, _i, _i, _i, C.c_float, C.c_float, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "seedmi_bench_stream_read": (_i, [_vp, C.c_size_t, _i, _vp, _vp]),
+    "seedmi_bench_mfma_bf16": (_i, [_i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
     "seedmi_preprocess_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "seedmi_preprocess_image_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         _vp, _i, _vp, _vp, C.c_size_t, _vp]),
@@ -100,6 +103,8 @@ SIGNATURES = {
     "seedmi_llama_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaWeights), _i, _i]),
     "seedmi_llama_forward": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.c_size_t, _vp]),
     "seedmi_llama_forward_ex": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, C.c_size_t, _vp]),
+    "seedmi_llama_forward_io": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, C.c_size_t,
+                                     _vp]),
 }
 
 

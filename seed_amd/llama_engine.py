@@ -130,31 +130,68 @@ class LlamaEngine:
     def reset(self):
         self.past_len = 0
 
-    def forward(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None, past_len: Optional[int] = None,
-                last_only: bool = False) -> torch.Tensor:
-        """input_ids int64 [B,T] on device.  Appends T positions to the static cache starting at ``past_len``
-        (default: continue from the previous call).  Returns bf16 logits [B, T or 1, vocab] (a view of a padded
-        buffer)."""
+    def forward(self, input_ids: Optional[torch.Tensor], position_ids: Optional[torch.Tensor] = None,
+                past_len: Optional[int] = None, last_only: bool = False, inputs_embeds: Optional[torch.Tensor] = None,
+                hidden_states_out: Optional[list] = None) -> torch.Tensor:
+        """input_ids int64 [B,T] on device (or ``inputs_embeds`` [B,T,hidden], llama_xformer.py:502-544).  Appends T positions to
+        the static cache starting at ``past_len`` (default: continue from the previous call).  Returns bf16 logits
+        [B, T or 1, vocab] (a view of a padded buffer).  ``hidden_states_out`` (a list, last_only False) receives the
+        layers+1 tensors [B,T,hidden] of ``output_hidden_states=True`` (:569-570, 613-617)."""
         cfg = self.cfg
-        if input_ids.dim() != 2:
-            raise ValueError("You have to specify input_ids of shape [batch, seq]")     # llama_xformer.py:515-522
-        B, T = input_ids.shape
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You have to specify exactly one of input_ids and inputs_embeds")       # llama_xformer.py:515-522
+        if input_ids is not None:
+            if input_ids.dim() != 2:
+                raise ValueError("You have to specify input_ids of shape [batch, seq]")
+            B, T = input_ids.shape
+            input_ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        else:
+            if inputs_embeds.dim() != 3 or inputs_embeds.shape[2] != cfg.hidden:
+                raise ValueError(f"inputs_embeds must be [batch, seq, {cfg.hidden}]")
+            B, T = inputs_embeds.shape[:2]
+            inputs_embeds = inputs_embeds.to(device=self.device, dtype=torch.bfloat16).contiguous()
         if past_len is None:
             past_len = self.past_len
         if position_ids is None:                                                          # llama_xformer.py:531-539
             position_ids = torch.arange(past_len, past_len + T, dtype=torch.int64, device=self.device).unsqueeze(0).expand(B, T)
-        position_ids = position_ids.reshape(B, T).to(torch.int64).contiguous()
-        input_ids = input_ids.to(torch.int64).contiguous()
+        position_ids = position_ids.reshape(B, T).to(device=self.device, dtype=torch.int64).contiguous()
         Tout = 1 if last_only else T
         logits = torch.empty(B * Tout, self.vocab_pad, dtype=torch.bfloat16, device=self.device)
+        hidden = None
+        if hidden_states_out is not None:
+            if last_only:
+                raise ValueError("hidden states are produced for all positions: last_only must be False")
+            hidden = torch.empty(cfg.layers + 1, B, T, cfg.hidden, dtype=torch.bfloat16, device=self.device)
         ws = self._workspace(B, T)
         with torch.cuda.device(self.device):
-            rc = self.lib.seedmi_llama_forward(C.byref(self.w), L.ptr(input_ids), L.ptr(position_ids), B, T, past_len,
-                                               1 if last_only else 0, L.ptr(logits), self.vocab_pad, L.ptr(ws),
-                                               ws.numel(), L.stream_ptr())
+            rc = self.lib.seedmi_llama_forward_io(C.byref(self.w), L.ptr(input_ids), L.ptr(inputs_embeds), L.ptr(position_ids),
+                                                  B, T, past_len, None, 1 if last_only else 0, L.ptr(logits), self.vocab_pad,
+                                                  L.ptr(hidden), L.ptr(ws), ws.numel(), L.stream_ptr())
         L.check(rc, "seedmi_llama_forward")
         self.past_len = past_len + T
+        if hidden is not None:
+            hidden_states_out.extend(hidden[i] for i in range(cfg.layers + 1))
         return logits.view(B, Tout, self.vocab_pad)[:, :, :cfg.vocab]
+
+    def resize_cache(self, batch_cap: Optional[int] = None, tmax: Optional[int] = None):
+        """Grow (or shrink) the static KV cache in place of a rebuild: the packed weights stay where they are, the cached
+        positions that fit are carried over.  Captured decode graphs of the old cache must not be replayed afterwards."""
+        cfg = self.cfg
+        nb, nt = batch_cap or self.batch_cap, tmax or self.tmax
+        if (nb, nt) == (self.batch_cap, self.tmax):
+            return self
+        cb, ct = min(nb, self.batch_cap), min(nt, self.tmax)
+        for i in range(cfg.layers):
+            for name, caches in (("k_cache", self.k_cache), ("v_cache", self.v_cache)):
+                new = torch.zeros(nb, cfg.heads, nt, cfg.head_dim, dtype=torch.bfloat16, device=self.device)
+                new[:cb, :, :ct] = caches[i][:cb, :, :ct]
+                caches[i] = new
+                setattr(self._layers[i], name, L.ptr(new))
+        self.batch_cap, self.tmax = nb, nt
+        self.w.batch_cap, self.w.tmax = nb, nt
+        self.past_len = min(self.past_len, nt)
+        self._ws, self._ws_key = None, (0, 0)
+        return self
 
     # ------------------------------------------------------------------ hipGraph decode loop
     def _decode_step_graphed(self, tok: torch.Tensor, logits: torch.Tensor, counter: torch.Tensor, ws: torch.Tensor):
@@ -174,11 +211,17 @@ class LlamaEngine:
         B = logits.shape[0]
         if logits.dtype != torch.bfloat16 or logits.stride(-1) != 1 or tok_out.dtype != torch.int64:
             raise ValueError("select_token: logits must be bf16 rows, tok_out int64")
+        # rows of ``uniforms`` / columns of ``history`` the device-side step may address (0 = no step-indexed buffer)
+        n_steps = 0
+        if history is not None:
+            n_steps = history.shape[1]
+        if uniforms is not None:
+            n_steps = uniforms.shape[0] if n_steps == 0 else min(n_steps, uniforms.shape[0])
         with torch.cuda.device(self.device):
             rc = self.lib.seedmi_sample_token_bf16(L.ptr(logits), logits.stride(0), B, self.cfg.vocab, float(temperature),
                                                    float(top_p), L.ptr(uniforms), L.ptr(step_dev), int(step_offset),
                                                    L.ptr(tok_out), L.ptr(history), 0 if history is None else history.stride(0),
-                                                   L.stream_ptr())
+                                                   n_steps, L.stream_ptr())
         L.check(rc, "seedmi_sample_token_bf16")
 
     def capture_decode_graph(self, first_tok: torch.Tensor, n_new: int, top_p: float = 0.0, temperature: float = 1.0,
@@ -220,10 +263,15 @@ class LlamaEngine:
         with torch.cuda.graph(graph):
             body()
         keep = (tok, counter, logits, ws, uniforms)          # buffers referenced by the graph
+        left = [n_new - 1]                                   # steps the capture was sized for (cache rows, uniforms, out)
 
         def replay(k: int):
+            if k < 0 or k > left[0]:
+                raise L.SeedmiError(f"replay({k}): only {left[0]} of the {n_new - 1} captured decode steps remain "
+                                    "(the graph writes the KV cache, `out` and reads `uniforms` by a device-side counter)")
             for _ in range(k):
                 graph.replay()
+            left[0] -= k
             self.past_len += k
             return keep and out
         return replay, out

@@ -66,8 +66,8 @@ def test_argument_validation_returns_status_codes_and_messages():
     assert l.seedmi_llama_attention_bf16(fake, 128, fake, fake, fake, 128, 1, 1, 1, 96, 64, 0, 0.1, 0, None, None) == E_SHAPE
     assert "128" in err()
     assert l.seedmi_gemm_skinny_bf16(65, 64, 128, fake, 128, fake, 128, None, 0, lib.EPI_NONE, fake, 64, None) == E_SHAPE
-    assert l.seedmi_sample_token_bf16(fake, 100, 2, 60000, 1.0, 0.5, None, None, 0, fake, None, 0, None) == E_SHAPE
-    assert l.seedmi_sample_token_bf16(fake, 100, 2, 100, 0.0, 0.5, None, None, 0, fake, None, 0, None) == E_SHAPE       # temperature 0
+    assert l.seedmi_sample_token_bf16(fake, 100, 2, 60000, 1.0, 0.5, None, None, 0, fake, None, 0, 0, None) == E_SHAPE
+    assert l.seedmi_sample_token_bf16(fake, 100, 2, 100, 0.0, 0.5, None, None, 0, fake, None, 0, 0, None) == E_SHAPE       # temperature 0
     mean = (C.c_float * 3)(0, 0, 0)
     assert l.seedmi_preprocess_image_u8(fake, 10, 10, 30, 8, 8, 5, 0, 0, 8, 8, mean, mean, fake, 1, None, fake, 1 << 20, None) == E_SHAPE
     assert l.seedmi_preprocess_image_u8(fake, 10, 10, 30, 8, 8, 3, 4, 0, 8, 8, mean, mean, fake, 1, None, fake, 1 << 20, None) == E_SHAPE

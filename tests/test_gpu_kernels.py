@@ -69,7 +69,7 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[128, 256, 232, 255], ids=["gemm128", "gemm256", "gemm256x32", "gemm256free"])
+@pytest.fixture(params=[128, 256], ids=["gemm128", "gemm256"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (128x128 two-barrier and 256x256 staggered deep pipeline)."""
     L.check(lib.seedmi_set_option(b"gemm", request.param), "set_option")
@@ -143,6 +143,58 @@ def test_gemm_epilogues(lib, gemm_variant, epi):
         C = run_gemm(lib, A, W, None, None, L.EPI_NONE)
         want = r(acc)
     assert_close_bf16(C, want, f"gemm_{epi}", frac=0.998)
+
+
+def test_gemm_gelu_epilogue_is_torch_gelu_bit_for_bit(lib, gemm_variant):
+    """The GELU epilogue is a bf16 -> bf16 table of torch's own nn.GELU() (tools/gen_gelu_lut.py): with an identity GEMM
+    (A = I, bias = 0) the output must EQUAL F.gelu(W^T) for every bf16 bit pattern, including the inputs outside the table
+    (|x| < 2^-16, |x| >= 16, zeros, infinities' neighbours) that take the polynomial path."""
+    K = 256
+    bits = torch.arange(0, 65536, dtype=torch.int32)
+    vals = (bits << 16).view(torch.float32)
+    keep = torch.isfinite(vals) & ((vals == 0) | (vals.abs() > 1e-37))          # (torch flushes bf16 subnormals in gelu)
+    vals = vals[keep].to(torch.bfloat16)
+    N = (vals.numel() + K - 1) // K
+    pad = torch.zeros(N * K - vals.numel(), dtype=torch.bfloat16)
+    W = torch.cat([vals, pad]).view(N, K).cuda()
+    A = torch.eye(K, K, dtype=torch.bfloat16, device="cuda")
+    C = run_gemm(lib, A, W, torch.zeros(N, dtype=torch.bfloat16, device="cuda"), None, L.EPI_BIAS_GELU)     # C = gelu(W^T)
+    want = torch.nn.functional.gelu(W.cpu()).t().contiguous()
+    got = C.cpu()
+    same = (got.view(torch.int16) == want.view(torch.int16)) | ((got == 0) & (want == 0))
+    in_table = (W.cpu().float().abs() >= 2.0 ** -16) & (W.cpu().float().abs() < 16)
+    print(f"[gelu table] {same.float().mean().item():.6f} equal; in-table mismatches {(~same.t() & in_table).sum().item()}")
+    assert not (~same.t() & in_table).any(), "table range must be bit-identical to torch"
+    assert_close_bf16(C, r(want.float()), "gelu outside the table", frac=0.9999)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(257 * 256, 1408, 1408, "residual"), (257 * 256 + 77, 1408, 768, "bias"),
+                                        (257 * 128, 4224, 1408, "bias"), (257 * 64, 6144, 1408, "gelu"),
+                                        (256 * 300, 768, 64, "bias")])
+def test_gemm_streamk_is_bit_identical_to_data_parallel(lib, M, N, K, epi):
+    """seedmi_gemm_bf16_ws: the last partial round of tiles is cut along K (stream-K); a shared tile's K tail CONTINUES the fp32
+    accumulator image its partner published, so every output equals the data-parallel launch bit for bit - and both match the
+    fp32 restatement.  Repeated launches reuse the workspace (epoch flags), as the tokenizer does."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = bf(rand(gen, M, K)).cuda()
+    W = bf(rand(gen, N, K, scale=0.04)).cuda()
+    bias = bf(rand(gen, N, scale=0.3)).cuda()
+    res = bf(rand(gen, M, N)).cuda() if epi == "residual" else None
+    code = {"residual": L.EPI_BIAS_RESIDUAL, "bias": L.EPI_BIAS, "gelu": L.EPI_BIAS_GELU}[epi]
+    ws = torch.empty(lib.seedmi_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    ws[:4096].zero_()
+    C0 = run_gemm(lib, A, W, bias, res, code)
+    for rep in range(3):
+        C1 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        rc = lib.seedmi_gemm_bf16_ws(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), 0 if res is None else N, code,
+                                     L.ptr(C1), N, 0, 0, L.ptr(ws), ws.numel(), L.stream_ptr())
+        L.check(rc, "seedmi_gemm_bf16_ws")
+        torch.cuda.synchronize()
+        assert torch.equal(C0.view(torch.int16), C1.view(torch.int16)), f"stream-K result differs from data-parallel (rep {rep})"
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])          # fp32 check on the first / last tiles' rows
+    acc = A[rows].float() @ W.float().t() + bias.float()
+    want = {"bias": r(acc), "gelu": r(gelu(r(acc))), "residual": r(r(acc) + (res[rows].float() if res is not None else 0))}[epi]
+    assert_close_bf16(C0[rows], want, f"gemm_streamk {M}x{N}x{K} {epi}", frac=0.998)
 
 
 def test_gemm_residual_inplace(lib, gemm_variant):
@@ -389,7 +441,7 @@ def test_rope_and_llama_attention(lib, prefill_variant, B, T, H, past):
     pos = torch.arange(past, past + T, dtype=torch.int64).unsqueeze(0).expand(B, T).contiguous().cuda()
     q_out = torch.empty(B * T, h, dtype=torch.bfloat16, device="cuda")
     rc = lib.seedmi_rope_kv_append(L.ptr(qkv), 3 * h, L.ptr(pos), L.ptr(cos_d), L.ptr(sin_d), L.ptr(q_out), h,
-                                   L.ptr(kc), L.ptr(vc), B, T, H, hd, tmax, past, None, L.stream_ptr())
+                                   L.ptr(kc), L.ptr(vc), B, T, H, hd, tmax, past, None, cos_d.shape[0], L.stream_ptr())
     L.check(rc, "rope_kv_append")
     torch.cuda.synchronize()
     qf = qkv[:, :h].float().view(B, T, H, hd).transpose(1, 2)
@@ -446,12 +498,12 @@ def test_fused_decode_attention_equals_rope_then_attention(lib, B, H, past, dev_
     out_a = torch.zeros(rows, h, dtype=torch.bfloat16, device="cuda")
     out_b = torch.zeros(rows, h, dtype=torch.bfloat16, device="cuda")
     L.check(lib.seedmi_rope_kv_append(L.ptr(qkv), 3 * h, L.ptr(pos), L.ptr(cos_d), L.ptr(sin_d), L.ptr(q_out), h, L.ptr(kc),
-                                      L.ptr(vc), B, T, H, hd, tmax, past, L.ptr(past_d), L.stream_ptr()), "rope")
+                                      L.ptr(vc), B, T, H, hd, tmax, past, L.ptr(past_d), cos_d.shape[0], L.stream_ptr()), "rope")
     L.check(lib.seedmi_llama_attention_bf16(L.ptr(q_out), h, L.ptr(kc), L.ptr(vc), L.ptr(out_a), h, B, T, H, hd, tmax, past, scale,
                                             1 if packed else 0, L.ptr(past_d), L.stream_ptr()), "attention")
     L.check(lib.seedmi_llama_decode_attention_bf16(L.ptr(qkv), 3 * h, L.ptr(pos), L.ptr(cos_d), L.ptr(sin_d), L.ptr(kc2), L.ptr(vc2),
                                                    L.ptr(out_b), h, B, H, hd, tmax, past, scale, 1 if packed else 0, L.ptr(past_d),
-                                                   L.stream_ptr()), "fused decode attention")
+                                                   cos_d.shape[0], L.stream_ptr()), "fused decode attention")
     torch.cuda.synchronize()
     assert torch.equal(kc, kc2) and torch.equal(vc, vc2), "cache append differs"
     assert torch.equal(out_a, out_b), "attention output differs"
@@ -485,7 +537,9 @@ def _unpack_activations(packed, rows, cols):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(32, 768, 512, "none"), (7, 1536, 1024, "swiglu"), (17, 512, 1408, "residual"),
-                                       (32, 12288, 4096, "none"), (64, 256, 256, "none")])
+                                       (32, 12288, 4096, "none"), (64, 256, 256, "none"),
+                                       # SEED-LLaMA-8B decode shapes (config 3): gate|up, down (K = 11008), lm_head (vocab 40194 -> 40208)
+                                       (32, 22016, 4096, "swiglu"), (32, 4096, 11008, "residual"), (32, 40208, 4096, "none")])
 def test_skinny_gemm_with_folded_rmsnorm(lib, M, N, K, epi):
     """seedmi_gemm_skinny_norm_bf16: un-normalised fragment-major rows in, weight * gamma streamed, row scale
     rsqrt(mean(x^2) + eps) applied to the fp32 accumulators; plus the fragment-major second copy of a residual result and

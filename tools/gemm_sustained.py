@@ -45,6 +45,14 @@ for name, M, N, K, epi in SHAPES:
             M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(R), N if R is not None else 0, epi, L.ptr(C), N, 0, 0,
             L.stream_ptr()), "gemm"))
     lib.seedmi_set_option(b"gemm", 0)
+    ws = torch.zeros(lib.seedmi_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    row["own_streamk"] = run(lambda: L.check(lib.seedmi_gemm_bf16_ws(
+        M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(R), N if R is not None else 0, epi, L.ptr(C), N, 0, 0,
+        L.ptr(ws), ws.numel(), L.stream_ptr()), "gemm ws"))
+    if epi != L.EPI_BIAS:       # what the vendor line computes (bias only): the price of the fused epilogue
+        row["own_streamk_bias_only"] = run(lambda: L.check(lib.seedmi_gemm_bf16_ws(
+            M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(C), N, 0, 0,
+            L.ptr(ws), ws.numel(), L.stream_ptr()), "gemm ws bias"))
     row["vendor_linear"] = run(lambda: torch.nn.functional.linear(A, W, bias))
     res[name] = row
     print(name, row, flush=True)

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Interleaved A/B of seedmi_tokenize at B = 256 under option sets (one process, several rounds, median ms per call):
+    python tools/tok_ab.py "tokenize_streams=2,gemm_streamk=1" "tokenize_streams=1,gemm_streamk=1" ..."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from seed_amd import config as C, lib as L  # noqa: E402
+from seed_amd.tokenizer_engine import TokenizerEngine  # noqa: E402
+from seed_amd.weights import make_tokenizer_state_dict  # noqa: E402
+
+lib = L.load()
+B = int(os.environ.get("B", "256"))
+ROUNDS = int(os.environ.get("ROUNDS", "4"))
+sets = sys.argv[1:] or ["tokenize_streams=2,gemm_streamk=1", "tokenize_streams=1,gemm_streamk=1", "tokenize_streams=2,gemm_streamk=0",
+                        "tokenize_streams=1,gemm_streamk=0"]
+sd = make_tokenizer_state_dict(C.SEED2, seed=0, device="cuda")
+eng = TokenizerEngine(sd, C.SEED2, device="cuda")
+del sd
+img = torch.randn(B, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)).bfloat16()
+defaults = {"tokenize_streams": 2, "gemm_streamk": 1, "gemm": 0, "gemm_group_m": 4}
+
+
+def apply(spec):
+    for k, v in defaults.items():
+        lib.seedmi_set_option(k.encode(), v)
+    for kv in spec.split(","):
+        if kv:
+            k, v = kv.split("=")
+            L.check(lib.seedmi_set_option(k.encode(), int(v)), kv)
+
+
+ref = None
+times = {s: [] for s in sets}
+for r in range(ROUNDS + 1):
+    for s in sets:
+        apply(s)
+        ids = eng.encode(img)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ids = eng.encode(img)
+        e1.record()
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = ids.clone()
+        assert torch.equal(ids, ref), f"ids differ under {s}"
+        if r > 0:
+            times[s].append(e0.elapsed_time(e1) / 3)
+apply("")
+res = {s: {"median_ms": round(sorted(t)[len(t) // 2], 3), "img_s": round(B / sorted(t)[len(t) // 2] * 1e3, 1), "all_ms": [round(x, 2) for x in t]}
+       for s, t in times.items()}
+print(json.dumps(res, indent=1))
+os.makedirs("gpurun_out/r02", exist_ok=True)
+json.dump(res, open("gpurun_out/r02/tok_ab.json", "w"), indent=1)
