@@ -48,7 +48,8 @@ int seedmi_check_device(void);
  * but they are not part of the per-stream thread-safety contract - set them before concurrent use; production callers leave the
  * defaults).  Keys (value): "gemm" (0 automatic | 128 | 256), "gemm_persist" (0|1), "gemm_streamk" (0|1: stream-K tail when a
  * workspace is passed), "gemm_group_m" (1..64 m-tiles per L2 tile group), "gemm_min_tiles" (256x256 kernel only at or above this
- * many tiles), "tokenize_streams" (1..4 concurrent sub-batches inside seedmi_tokenize), "skinny_nt" / "skinny_waves" / "skinny_rows"
+ * many tiles), "tokenize_streams" (1..4 concurrent sub-batches inside seedmi_tokenize), "tokenize_streamk" (0|1: stream-K
+ * tail for the tokenizer's big GEMMs, default 0), "skinny_nt" / "skinny_waves" / "skinny_rows"
  * (decode GEMM), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
  * (attention kernel selection).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */

@@ -7,10 +7,13 @@
 //     V(i+1) right after PV(i)                 (lands during QK^T(i+1)),
 //     Q(i+1) travels with K(i+1) into its own LDS image (no ordinary global loads inside the loop: vmcnt retires in
 //     order, and a register load younger than V(i+1)'s DMA would make its consumer wait for V as well).
-// K and V live in LDS row-major with UNPADDED 176-byte rows (11 x 16 B: an odd number of 16-byte slots keeps
-// ds_read_b128 / ds_read_b64_tr_b16 at <= 2-way conflicts) because LDS-DMA writes lane-linear images; the head
-// dim is padded to 96 on the register side instead: the Q fragment's last 16-byte chunk is zero, so whatever the
-// K read picks up from the next row is multiplied by 0, and the spilled V columns 88..95 are never stored.
+// K, Q and V live in LDS row-major with 192-byte rows (12 x 16 B: head dim padded to 96) whose 16-byte chunks are XOR-swizzled
+// inside each aligned group of four: chunk c of row r sits at position c ^ T[(r >> 2) & 3], T = {0,2,3,1}.  With that every
+// ds_read_b128 of a K / Q fragment (16 rows x one chunk column per 16-lane group) and every ds_read_b64_tr_b16 of a V fragment
+// (8 rows x two chunks per half wave) touches each bank once: the round-1 image (unpadded 176-byte rows) was 2-way on every one of
+// them (SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE, profiles/r02_pmc_attention_head.json).  LDS-DMA writes lane-linear images, so
+// the permutation is applied to the per-lane SOURCE chunk.  The 12th chunk (columns 88..95) is a copy of the 11th: the Q
+// fragment's 12th chunk is zeroed in registers, so it is multiplied by 0, and V columns 88..95 are never stored.
 // Same arithmetic and rounding points as attn_fullrow.hip (q*scale -> half, S -> half, P normalised -> half).
 #include <string.h>
 #include "common.h"
@@ -18,11 +21,15 @@
 
 namespace {
 
-constexpr int VHD = 88, VCH = 11, VNKP = 288, VNT = 18, VKK = 9, VHT = 6;
-constexpr int VROWS = VNKP + 1;                         // one spill row for the 96-wide reads of the last key
+constexpr int VHD = 88, VCH = 11, VNKP = 288, VNT = 17, VKK = 9, VHT = 6;
+constexpr int VLD = 96, VCHL = 12;                      // LDS row: 96 elements = 12 chunks of 16 B
 constexpr int VWAVES = 12;
 constexpr int VMAXT = 2;                                // q-tiles per wave: tiles w, w+12 (n <= 272 -> 17 tiles)
-constexpr int VMAT_BYTES = VROWS * VHD * 2;             // 50,864 B per matrix image (K, Q, V: 152.6 KB of LDS)
+constexpr int VKQ_ROWS = 16 * VNT;                      // 272 rows of K and of Q are ever read
+constexpr int VKQ_BYTES = VKQ_ROWS * VLD * 2;           // 52,224 B
+constexpr int VV_BYTES = VNKP * VLD * 2;                // 55,296 B: PV walks 9 x 32 keys
+constexpr int VLDS_BYTES = 2 * VKQ_BYTES + VV_BYTES;    // 159,744 B
+SEEDMI_DEVINL int vswz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
 struct VitAttnParams {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
@@ -58,20 +65,21 @@ template <bool ROUND_S, int NFIX>
 __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ksm = (bf16_t*)smem;
-    bf16_t* Qsm = (bf16_t*)(smem + VMAT_BYTES);
-    bf16_t* Vsm = (bf16_t*)(smem + 2 * VMAT_BYTES);
+    bf16_t* Qsm = (bf16_t*)(smem + VKQ_BYTES);
+    bf16_t* Vsm = (bf16_t*)(smem + 2 * VKQ_BYTES);
     const int tid = threadIdx.x;
     const int lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = NFIX > 0 ? NFIX : p.n;
-    const int total_chunks = n * VCH;
+    const int total_chunks = n * VCHL;
     const int npieces = (total_chunks + 63) >> 6;                     // 1 KiB LDS-DMA pieces per matrix (<= 48)
     const int my_pieces = (npieces - wave + VWAVES - 1) / VWAVES;     // pieces wave, wave+8, ... (wave-uniform, <= 6)
     const int nqt = (n + 15) >> 4;
     const int my_tiles = (nqt - wave + VWAVES - 1) / VWAVES;          // q-tiles wave, wave+8, wave+16
 
-    // V image: rows >= n must hold finite values (they meet P == 0); zero the whole image once
-    for (int i = tid; i < VMAT_BYTES / 16; i += 64 * VWAVES) *(uint4*)(smem + 2 * VMAT_BYTES + 16 * i) = make_uint4(0, 0, 0, 0);
+    // V rows >= n must hold finite values (they meet P == 0) and K / Q rows >= n are read too (their scores are overwritten, their
+    // output rows never stored): clear all of LDS once, the DMA only ever writes rows < n
+    for (int i = tid; i < VLDS_BYTES / 16; i += 64 * VWAVES) *(uint4*)(smem + 16 * i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     auto stage = [&](const bf16_t* base, int ld, bf16_t* dst, int item) {
@@ -79,8 +87,9 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
         const bf16_t* src = base + (size_t)b * n * ld + h * VHD;
         for (int j = 0; j < my_pieces; ++j) {
             const int piece = wave + VWAVES * j;
-            const int q = min(64 * piece + lane, total_chunks - 1);  // clamped lanes copy a valid (finite) chunk
-            const int row = q / VCH, c = q - row * VCH;
+            const int q = min(64 * piece + lane, total_chunks - 1);  // LDS chunk position (clamped lanes rewrite the last one)
+            const int row = q / VCHL;
+            const int c = min((q - row * VCHL) ^ vswz(row), VCH - 1);   // source chunk of that position; the pad chunk copies the 11th
             glds16v(src + (size_t)row * ld + 8 * c, (char*)dst + piece * 1024);
         }
     };
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {            // q * scale rounded to half; the 12th chunk (cols 88..95) is zero
                     uint4 v = make_uint4(0, 0, 0, 0);
-                    if (32 * ks + 8 * g < VHD) v = *(const uint4*)(Qsm + (16 * qt + li) * VHD + 32 * ks + 8 * g);
+                    if (32 * ks + 8 * g < VHD) v = *(const uint4*)(Qsm + (16 * qt + li) * VLD + 8 * ((4 * ks + g) ^ vswz(li)));
                     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) w[i] = pack2bf(lo_bf(w[i]) * p.scale, hi_bf(w[i]) * p.scale);
@@ -123,11 +132,13 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int ks = 0; ks < 3; ++ks)
-                            f[3 * u + ks] = *(const bf16x8*)(Ksm + (16 * (2 * grp + u) + li) * VHD + 32 * ks + 8 * g);
+                            if (2 * grp + u < VNT)
+                                f[3 * u + ks] = *(const bf16x8*)(Ksm + (16 * (2 * grp + u) + li) * VLD + 8 * ((4 * ks + g) ^ vswz(li)));
                 };
                 auto mmk = [&](bf16x8 (&f)[6], int grp) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
+                        if (2 * grp + u >= VNT) continue;
                         s[2 * grp + u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int ks = 0; ks < 3; ++ks)
@@ -136,12 +147,12 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
                 };
                 ldk(fk0, 0);
 #pragma unroll
-                for (int grp = 0; grp < VNT / 2; ++grp) {
+                for (int grp = 0; grp < (VNT + 1) / 2; ++grp) {
                     if (grp & 1) {
-                        if (grp + 1 < VNT / 2) ldk(fk0, grp + 1);
+                        if (grp + 1 < (VNT + 1) / 2) ldk(fk0, grp + 1);
                         mmk(fk1, grp);
                     } else {
-                        if (grp + 1 < VNT / 2) ldk(fk1, grp + 1);
+                        if (grp + 1 < (VNT + 1) / 2) ldk(fk1, grp + 1);
                         mmk(fk0, grp);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -188,8 +199,11 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
                     uint4 pw;
                     pw.x = pack2bf(s[2 * kk][0] * inv, s[2 * kk][1] * inv);
                     pw.y = pack2bf(s[2 * kk][2] * inv, s[2 * kk][3] * inv);
-                    pw.z = pack2bf(s[2 * kk + 1][0] * inv, s[2 * kk + 1][1] * inv);
-                    pw.w = pack2bf(s[2 * kk + 1][2] * inv, s[2 * kk + 1][3] * inv);
+                    pw.z = pw.w = 0u;                                  // (keys 272..287 do not exist: P = 0)
+                    if (2 * kk + 1 < VNT) {
+                        pw.z = pack2bf(s[2 * kk + 1][0] * inv, s[2 * kk + 1][1] * inv);
+                        pw.w = pack2bf(s[2 * kk + 1][2] * inv, s[2 * kk + 1][3] * inv);
+                    }
                     pf[t][kk] = __builtin_bit_cast(bf16x8, pw);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -218,9 +232,10 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
                 auto ldv = [&](bf16x8 (&f)[VHT], int kk) {
 #pragma unroll
                     for (int nn = 0; nn < VHT; ++nn) {
-                        const bf16_t* vp = Vsm + (32 * kk + 4 * g + (li >> 2)) * VHD + 16 * nn + 4 * (li & 3);
+                        // rows 32kk + 4g + (li>>2) and + 16: both have (row >> 2) & 3 == g, i.e. the same chunk permutation
+                        const bf16_t* vp = Vsm + (32 * kk + 4 * g + (li >> 2)) * VLD + 8 * ((2 * nn + ((li & 3) >> 1)) ^ vswz(4 * g)) + 4 * (li & 1);
                         const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
-                        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 16 * VHD));
+                        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 16 * VLD));
                         const uint2 lo = __builtin_bit_cast(uint2, a), hi = __builtin_bit_cast(uint2, c);
                         f[nn] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
                     }
@@ -274,7 +289,7 @@ int seedmi_attn_vit_set(int v) { g_attn_vit = v; return SEEDMI_OK; }
 int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                              int batch, int heads, int head_dim, int nq, int nk, float scale, int causal, int round_scores,
                              void* stream) {
-    if (!g_attn_vit || head_dim != VHD || causal || nq != nk || nk > VNKP - 16 || nk < 64) return 1;
+    if (!g_attn_vit || head_dim != VHD || causal || nq != nk || nk > 16 * VNT || nk < 64) return 1;
     VitAttnParams p;
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
@@ -286,7 +301,7 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     const int grid = p.items < n_cu ? p.items : n_cu;
-    constexpr int lds = 3 * VMAT_BYTES;
+    constexpr int lds = VLDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -42,6 +42,8 @@ std::atomic<int> g_gemm_ablate{0};   // "gemm_ablate": timing-only ablations (de
 std::atomic<int> g_group_m{4};       // "gemm_group_m": m-tiles per L2 tile group
 std::atomic<int> g_gemm_persist{1};  // "gemm_persist": persistent one-workgroup-per-CU launch of the 256x256 kernel
 std::atomic<int> g_gemm_streamk{1};  // "gemm_streamk": stream-K tail when the caller passes a workspace
+std::atomic<int> g_gemm_prefetch_r{0};   // "gemm_prefetch_residual": residual tile touched during the K loop (measured neutral: off)
+std::atomic<int> g_gemm_residual_nt{1};  // "gemm_residual_nt": streaming stores for the BIAS_RESIDUAL output
 std::atomic<int> g_gemm_variant{0};  // "gemm": 0 = auto, 128 / 256 = force a kernel
 std::atomic<int> g_gemm_min_tiles{160};   // "gemm_min_tiles": fewer 256x256 tiles than this -> 128x128 kernel
 
@@ -64,6 +66,8 @@ struct GemmParams {
     float* sk_slabs;
     unsigned* sk_flags;
     unsigned sk_epoch;
+    int prefetch_residual;      // BIAS_RESIDUAL on the 256x256 kernel: touch the residual tile during the K loop ("gemm_prefetch_residual")
+    int residual_nt;            // BIAS_RESIDUAL output stores: 1 = streaming (non-temporal), 0 = ordinary ("gemm_residual_nt")
     int row_group, row_extra;   // patch-embed: out_row = m + (m / row_group) * row_extra + row_extra ; res_row = m % row_group + row_extra
 };
 
@@ -129,9 +133,13 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
         }
     }
     // residual / pos_embed rows of ALL the lane's rows are requested up front: one exposed HBM latency per tile instead
-    // of one per row (the per-row form serialised 8 round trips and cost the proj GEMM 25 %)
-    uint4 rr[MT][2];
-    if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_PATCH_EMBED) {
+    // of one per row (the per-row form serialised 8 round trips and cost the proj GEMM 25 %).  With 8 row groups that is 64
+    // registers: the 256x256 kernel's BIAS_RESIDUAL tiles take gemm_epilogue_residual8 instead and only ragged edges come here,
+    // row by row.
+    constexpr bool RES = (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_PATCH_EMBED);
+    constexpr bool PREFETCH_R = RES && !(EPI == EPI_BIAS_RESIDUAL && MT > 4);
+    uint4 rr[PREFETCH_R ? MT : 1][2];
+    if (PREFETCH_R) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const int m = min(mrow0 + 16 * mi + li, p.M - 1);
@@ -194,8 +202,8 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             }
             const bf16_t* rp = p.R + (size_t)res_row * p.ldr + nb;
             if (full) {
-                const uint4 r0 = rr[mi][0];
-                const uint4 r1 = rr[mi][1];
+                const uint4 r0 = PREFETCH_R ? rr[PREFETCH_R ? mi : 0][0] : *(const uint4*)rp;
+                const uint4 r1 = PREFETCH_R ? rr[PREFETCH_R ? mi : 0][1] : *(const uint4*)(rp + 8);
                 const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -265,6 +273,96 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                     if (nb + i < p.N) cp[i] = (EPI == EPI_BIAS_GELU && packed) ? (bf16_t)((pk[i >> 1] >> (16 * (i & 1))) & 0xffffu) : f2bf(v[i]);
             }
         }
+    }
+}
+
+// BIAS_RESIDUAL epilogue of the 256x256 kernel (8 row groups per lane) for a wave whose 64-column span lies inside N.
+// Same arithmetic as gemm_epilogue<EPI_BIAS_RESIDUAL, 8>, ordered for the memory pipe: vmcnt retires in order and hipcc waits
+// vmcnt(0) for every ordinary load while LDS-DMA is in flight, so a load issued AFTER the tile's first stores (a second batch of
+// residual rows, a register reloaded from scratch) waits for those stores to reach memory - microseconds each.  The generic
+// form needed 64 registers for the residual rows, spilled, and paid exactly that: +87 us on the ViT proj GEMM, +68 us on fc2 at
+// B = 256 over the bias-only epilogue.  Here the residual rows are fetched in two halves of 32 registers and the first half's
+// finished rows are HELD (packed, 32 registers, while their accumulators die) until the second half's loads have been issued: every
+// load of the epilogue precedes every store, nothing spills.
+SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const int span0 = nb & ~63;
+    float bias[16];
+    {
+        const uint4 b0 = p.bias ? *(const uint4*)(p.bias + nb) : make_uint4(0, 0, 0, 0);
+        const uint4 b1 = p.bias ? *(const uint4*)(p.bias + nb + 8) : make_uint4(0, 0, 0, 0);
+        const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { bias[2 * i] = lo_bf(bw[i]); bias[2 * i + 1] = hi_bf(bw[i]); }
+    }
+    uint4 rr[4][2];
+    auto load_rows = [&](int h) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const bf16_t* rp = p.R + (size_t)min(mrow0 + 16 * (4 * h + mi) + li, p.M - 1) * p.ldr + nb;
+            rr[mi][0] = *(const uint4*)rp;
+            rr[mi][1] = *(const uint4*)(rp + 8);
+        }
+    };
+    // finished row (packed, lane-transposed so that a store instruction writes 64 contiguous bytes of a row)
+    auto finish_row = [&](int mi_abs, int mi_rr, u32x4_t& oa, u32x4_t& oc) {
+        const uint4 r0 = rr[mi_rr][0], r1 = rr[mi_rr][1];
+        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[mi_abs][ni][r] + bias[4 * ni + r];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[2 * i] = rbf(v[2 * i]) + lo_bf(rw[i]);               // half GEMM output + half residual
+            v[2 * i + 1] = rbf(v[2 * i + 1]) + hi_bf(rw[i]);
+        }
+        unsigned a[4] = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        unsigned c[4] = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const auto t1 = __builtin_amdgcn_permlane16_swap(a[d], c[d], false, false);
+            const auto t2 = __builtin_amdgcn_permlane32_swap(t1[0], t1[1], false, false);
+            a[d] = t2[0];
+            c[d] = t2[1];
+        }
+        oa = (u32x4_t){a[0], a[1], a[2], a[3]};
+        oc = (u32x4_t){c[0], c[1], c[2], c[3]};
+    };
+    auto store_row = [&](int mi_abs, const u32x4_t& oa, const u32x4_t& oc) {
+        const int m = mrow0 + 16 * mi_abs + li;
+        if (m < p.M) {
+            bf16_t* wp = p.C + (size_t)m * p.ldc + span0 + 8 * ((nb >> 4) & 3);
+            if (p.residual_nt) {
+                __builtin_nontemporal_store(oa, (u32x4_t*)wp);
+                __builtin_nontemporal_store(oc, (u32x4_t*)(wp + 32));
+            } else {                                              // the residual stream is re-read soon: let it allocate in the caches
+                *(u32x4_t*)wp = oa;
+                *(u32x4_t*)(wp + 32) = oc;
+            }
+        }
+    };
+    u32x4_t ha[4], hc[4];
+    load_rows(0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) finish_row(mi, mi, ha[mi], hc[mi]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(1);                                                 // the last loads of the epilogue ...
+    // ... must have LANDED before the first store is issued (a later wait for them would also wait for the stores in front of it):
+    // an empty asm that "reads" the loaded registers makes the compiler place its vmcnt wait here
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+        asm volatile("" : "+v"(rr[mi][0].x), "+v"(rr[mi][0].y), "+v"(rr[mi][0].z), "+v"(rr[mi][0].w), "+v"(rr[mi][1].x), "+v"(rr[mi][1].y),
+                     "+v"(rr[mi][1].z), "+v"(rr[mi][1].w));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) store_row(mi, ha[mi], hc[mi]);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        u32x4_t oa, oc;
+        finish_row(4 + mi, mi, oa, oc);
+        store_row(4 + mi, oa, oc);
     }
 }
 
@@ -382,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 constexpr int B2 = 256;
 constexpr int MAX_SEGS = 512;                     // segment list of one workgroup in LDS (6 KiB)
 constexpr int SEG_BYTES = MAX_SEGS * 3 * 4;
+constexpr int SCRATCH_BYTES = 8 * 256;            // one 256-byte LDS-DMA landing row per wave (residual prefetch touches)
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;          // 64 KiB per K-tile
 
@@ -415,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // The segment list (tile, first K-tile, end K-tile) of this workgroup is written to LDS once (behind the operand ring and the
     // activation table) and read back one entry per tile: the walk then costs two SGPRs of state instead of a dozen.
     int* const segs = (int*)(smem + 2 * KT_BYTES + GELU_LUT_BYTES);
+    constexpr int SCRATCH_OFF = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES;
     int n_seg = 0;
     {
         const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
@@ -567,6 +667,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
         if (kt + 1 < ke) stageA(kt + 1);
+        if (EPI == EPI_BIAS_RESIDUAL && p.prefetch_residual) {
+            // The epilogue reads this tile's 128 KB of residual.  Left to the epilogue, all CUs ask HBM for their tiles in the same
+            // few microseconds (32 MB per round) while C goes the other way: measured +81 us on the proj GEMM, +68 us on fc2 (B = 256)
+            // over the bias-only epilogue.  Touch the wave's 128 x 128-byte residual block in four pieces spread over the last twelve
+            // K-tiles instead (one dword per 64-byte line by LDS-DMA into a scratch row: no VGPR destination, retired by this
+            // K-tile's own vmcnt(0) three phases later), so the lines wait in the Infinity Cache / L2 when the epilogue asks.
+            const int rem = ke - 1 - kt;
+            if (rem == 12 || rem == 9 || rem == 6 || rem == 3) {
+                const int j = (12 - rem) / 3;
+                const int col = n0 + 64 * wn + 32 * (j & 1);
+                if (col < p.N) {
+                    const int row = min(m0 + 128 * wm + 64 * (j >> 1) + lane, p.M - 1);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.R + (size_t)row * p.ldr + col),
+                                                     (__attribute__((address_space(3))) void*)(smem + SCRATCH_OFF + wave * 256), 4, 0, 0);
+                }
+            }
+        }
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -667,8 +784,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __syncthreads();
         if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        if (p.skip_epilogue != 1) gemm_epilogue<EPI, 8>(p, acc, em0 + 128 * wm, en0 + 64 * wn + 16 * g, li, lut);
-        else if (acc[0][0][0] == 123.456f) p.C[0] = 0;      // keep the accumulators alive
+        const int enb = en0 + 64 * wn + 16 * g;
+        if (EPI == EPI_BIAS_RESIDUAL && p.skip_epilogue == 0 && (enb & ~63) + 64 <= p.N) {
+            gemm_epilogue_residual8(p, acc, em0 + 128 * wm, enb, li);
+        } else if (p.skip_epilogue != 1) {
+            gemm_epilogue<EPI, 8>(p, acc, em0 + 128 * wm, enb, li, lut);
+        } else if (acc[0][0][0] == 123.456f) {
+            p.C[0] = 0;                                     // keep the accumulators alive
+        }
     }
     if (!more) break;
     }
@@ -701,7 +824,7 @@ std::atomic<unsigned> g_sk_epoch{0};
 
 template <int EPI>
 int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_bytes) {
-    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES;
+    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES;
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
@@ -791,7 +914,16 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_streamk = value;
         return SEEDMI_OK;
     }
+    if (key && !strcmp(key, "gemm_prefetch_residual") && (value == 0 || value == 1)) {
+        g_gemm_prefetch_r = value;
+        return SEEDMI_OK;
+    }
+    if (key && !strcmp(key, "gemm_residual_nt") && (value == 0 || value == 1)) {
+        g_gemm_residual_nt = value;
+        return SEEDMI_OK;
+    }
     if (key && !strcmp(key, "tokenize_streams") && seedmi_tokenizer_set_streams(value) == SEEDMI_OK) return SEEDMI_OK;
+    if (key && !strcmp(key, "tokenize_streamk") && seedmi_tokenizer_set_streamk(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_llama_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_attn_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);

@@ -33,6 +33,8 @@ struct TokWs {
     size_t bytes;
 };
 
+int g_tok_streamk = 0;                    // seedmi_set_option("tokenize_streamk", 0|1)
+
 TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
     const int grid = w->img_size / w->patch;
     const size_t P = (size_t)grid * grid, NT = P + 1;
@@ -87,9 +89,13 @@ struct Part {
 // phases: 0 = patch embed; 1..depth = ViT blocks; depth+1 = ln_vision + query expand; then Q-Former layers; last = head + VQ
 int n_phases(const seedmi_tokenizer_weights_t* w) { return 1 + w->vit_depth + 1 + w->qf_layers + 1; }
 
-// big GEMMs (M = B * 257 rows) take the stream-K workspace; the small Q-Former ones run on the 128x128 kernel anyway
+// big GEMMs (M = B * 257 rows): with seedmi_set_option("tokenize_streamk", 1) they take the stream-K workspace.  Off by default:
+// measured at B = 256 (tools/tok_ab.py, profiles/r02_tok_ab.json) the two sub-batch streams already fill every kernel's partial last
+// round with the other stream's workgroups (134.9 ms per pass), and stream-K's balanced endings take that overlap away (141.5 ms);
+// on one stream it is neutral (140.6 vs 140.8 ms).  It pays for isolated GEMM calls (seedmi_gemm_bf16_ws: +2..4 %).
 #define GEMM_WS(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, rg_, re_) \
-    seedmi_gemm_bf16_ws(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, rg_, re_, t.sk, t.sk_bytes, s)
+    seedmi_gemm_bf16_ws(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, rg_, re_, g_tok_streamk ? t.sk : nullptr, \
+                        g_tok_streamk ? t.sk_bytes : 0, s)
 
 int run_phase(const Part& p, int phase) {
     const seedmi_tokenizer_weights_t* w = p.w;
@@ -206,6 +212,11 @@ int seedmi_tokenizer_set_streams(int n) {
     g_tok_streams = n;
     return SEEDMI_OK;
 }
+int seedmi_tokenizer_set_streamk(int v) {
+    if (v != 0 && v != 1) return SEEDMI_E_SHAPE;
+    g_tok_streamk = v;
+    return SEEDMI_OK;
+}
 
 extern "C" size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int batch) {
     if (!w || batch <= 0) return 0;
@@ -266,8 +277,9 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
             HIPCK(hipStreamWaitEvent(g_fj.side[i - 1], g_fj.fork, 0));
         }
     }
-    for (int i = 0; i < nparts; ++i)     // stream-K flags: a cleared word never equals a launch's epoch
-        HIPCK(hipMemsetAsync(parts[i].t.sk, 0, 4096, parts[i].s));
+    if (g_tok_streamk)
+        for (int i = 0; i < nparts; ++i)     // stream-K flags: a cleared word never equals a launch's epoch
+            HIPCK(hipMemsetAsync(parts[i].t.sk, 0, 4096, parts[i].s));
     const int np = n_phases(w);
     for (int ph = 0; ph < np; ++ph)
         for (int i = 0; i < nparts; ++i) CK(run_phase(parts[i], ph));

@@ -168,7 +168,10 @@ def test_llama8b_width_parity_with_oracle(fold_norm):
         if i in (1, 2, 8):
             _check_logits(lg[:, 0], s32[:, i], s16[:, i], f"8B-width decode step {i} fold={fold_norm}")
     torch.cuda.synchronize()
-    assert _rel(eng.k_cache[1][:B, :, :T0].float(), p32[1][0][:, :, :T0]) < 1e-2           # post-RoPE keys, reference layout
+    # post-RoPE keys in the reference's cache layout: no further from the fp32 oracle than 1.5x the bf16 oracle's own distance
+    ek, ek16 = _rel(eng.k_cache[1][:B, :, :T0].float(), p32[1][0][:, :, :T0]), _rel(p16[1][0][:, :, :T0], p32[1][0][:, :, :T0])
+    print(f"[8B-width layer-1 keys fold={fold_norm}] rel vs fp32 oracle: hip {ek:.3e} / bf16-oracle {ek16:.3e}")
+    assert ek < max(1.5 * ek16, 5e-3), (ek, ek16)
     # free-running greedy: eager loop and hipGraph replay vs the fp32 oracle on confident rows
     top2 = s32.topk(2, dim=-1).values
     confident = (top2[..., 0] - top2[..., 1]) > 1e-2 * s32.abs().amax(-1)

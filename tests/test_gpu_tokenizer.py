@@ -93,10 +93,12 @@ def test_tokenizer_matches_oracle_and_reference_golden(golden_dir, name, cfg):
         eng.encode(torch.zeros(1, 3, cfg.img_size + 14, cfg.img_size, device="cuda"))
 
 
-# Measured on MI355X (round 2, profiles/r02_id_agreement.json): the thresholds below sit two points under what was observed.
-FULL_AGREE_HIP_VS_ORACLE_BF16 = 0.90
-FULL_AGREE_HIP_VS_REFERENCE_BF16 = 0.85
-FULL_AGREE_HIP_VS_REFERENCE_FP32 = 0.85
+# Measured on MI355X (round 2, profiles/r02_id_agreement.json: 16 full-size images, 512 ids): HIP vs the reference modules' bf16 run
+# 0.9414, vs their fp32 run 0.9277 (the reference's own bf16 run agrees with its fp32 run on 0.9316); HIP vs the bf16 oracle 0.9141
+# (4 images).  Every differing id sits on a near-tie row.  The thresholds below are two points under what was observed.
+FULL_AGREE_HIP_VS_ORACLE_BF16 = 0.89
+FULL_AGREE_HIP_VS_REFERENCE_BF16 = 0.92
+FULL_AGREE_HIP_VS_REFERENCE_FP32 = 0.905
 
 
 def test_tokenizer_full_size_seed2(golden_dir):
@@ -130,7 +132,7 @@ def test_tokenizer_full_size_seed2(golden_dir):
           f"id agreement: hip-fp32ref {a32:.4f}, hip-bf16ref {a16:.4f}, bf16ref-fp32ref {aref:.4f}")
     assert _rel(emb, torch.from_numpy(g["image_embeds_fp32_slice"])) < 2e-2
     assert e32 < max(1.5 * eref, 3e-3), (e32, eref)                  # no further from the reference's fp32 run than its own bf16 run
-    assert a16 >= min(FULL_AGREE_HIP_VS_REFERENCE_BF16, aref - 0.05) and a32 >= min(FULL_AGREE_HIP_VS_REFERENCE_FP32, aref - 0.05)
+    assert a16 >= FULL_AGREE_HIP_VS_REFERENCE_BF16 and a32 >= FULL_AGREE_HIP_VS_REFERENCE_FP32, (a16, a32)
     # every id that differs from the reference's fp32 ids is a near-tie: the reference's own top-2 distance gap on that row is within
     # the perturbation the measured z difference can cause
     cb = sd["quantize.embedding.weight"].float()

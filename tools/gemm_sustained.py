@@ -53,6 +53,14 @@ for name, M, N, K, epi in SHAPES:
         row["own_streamk_bias_only"] = run(lambda: L.check(lib.seedmi_gemm_bf16_ws(
             M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(C), N, 0, 0,
             L.ptr(ws), ws.numel(), L.stream_ptr()), "gemm ws bias"))
+    if epi == L.EPI_BIAS_RESIDUAL:
+        lib.seedmi_set_option(b"gemm_prefetch_residual", 0)
+        row["own_256_no_residual_prefetch"] = run(lambda: L.check(lib.seedmi_gemm_bf16(
+            M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(R), N, epi, L.ptr(C), N, 0, 0, L.stream_ptr()), "gemm"))
+        lib.seedmi_set_option(b"gemm_prefetch_residual", 1)
+        # diagnosis: the same epilogue with an L2-resident residual (every row reads the same 2.8 KB: ldr = 0)
+        row["own_256_residual_ldr0"] = run(lambda: L.check(lib.seedmi_gemm_bf16(
+            M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(R), 0, epi, L.ptr(C), N, 0, 0, L.stream_ptr()), "gemm"))
     row["vendor_linear"] = run(lambda: torch.nn.functional.linear(A, W, bias))
     res[name] = row
     print(name, row, flush=True)

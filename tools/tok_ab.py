@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Interleaved A/B of seedmi_tokenize at B = 256 under option sets (one process, several rounds, median ms per call):
-    python tools/tok_ab.py "tokenize_streams=2,gemm_streamk=1" "tokenize_streams=1,gemm_streamk=1" ..."""
+    python tools/tok_ab.py "tokenize_streams=2,tokenize_streamk=1" "tokenize_streams=1,tokenize_streamk=1" ..."""
 import json
 import os
 import sys
@@ -15,13 +15,13 @@ from seed_amd.weights import make_tokenizer_state_dict  # noqa: E402
 lib = L.load()
 B = int(os.environ.get("B", "256"))
 ROUNDS = int(os.environ.get("ROUNDS", "4"))
-sets = sys.argv[1:] or ["tokenize_streams=2,gemm_streamk=1", "tokenize_streams=1,gemm_streamk=1", "tokenize_streams=2,gemm_streamk=0",
-                        "tokenize_streams=1,gemm_streamk=0"]
+sets = sys.argv[1:] or ["tokenize_streams=2,tokenize_streamk=1", "tokenize_streams=1,tokenize_streamk=1", "tokenize_streams=2,tokenize_streamk=0",
+                        "tokenize_streams=1,tokenize_streamk=0"]
 sd = make_tokenizer_state_dict(C.SEED2, seed=0, device="cuda")
 eng = TokenizerEngine(sd, C.SEED2, device="cuda")
 del sd
 img = torch.randn(B, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)).bfloat16()
-defaults = {"tokenize_streams": 2, "gemm_streamk": 1, "gemm": 0, "gemm_group_m": 4}
+defaults = {"tokenize_streams": 2, "tokenize_streamk": 0, "gemm": 0, "gemm_group_m": 4, "gemm_prefetch_residual": 1}
 
 
 def apply(spec):
