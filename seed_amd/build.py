@@ -44,6 +44,23 @@ def _compile(src, force, objdir=OBJ, extra=()):
     return obj, True
 
 
+def build_variant(name: str, defines, verbose: bool = True) -> str:
+    """A/B build of the product library with extra -D flags: seed_amd/libseedmi_<name>.so (tools select it with SEEDMI_LIB_PATH)."""
+    objdir = OBJ + "_" + name
+    lib = os.path.join(HERE, f"libseedmi_{name}.so")
+    os.makedirs(objdir, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(lambda s: _compile(s, False, objdir, tuple(defines)), SOURCES))
+    objs = [o for o, _ in results]
+    if any(changed for _, changed in results) or not os.path.exists(lib):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[seed_amd.build] linked {lib}")
+    return lib
+
+
 def build(force: bool = False, verbose: bool = True, devtools: bool = False) -> str:
     """devtools=True builds libseedmi_dev.so with -DSEEDMI_DEVTOOLS: the product library plus timing-only ablation switches,
     rejected kernel variants and micro-benchmarks that tools/ scripts use (SEEDMI_LIB_PATH selects it); never loaded by the
@@ -69,4 +86,8 @@ def build(force: bool = False, verbose: bool = True, devtools: bool = False) -> 
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, devtools="--devtools" in sys.argv)
+    if "--variant" in sys.argv:          # python -m seed_amd.build --variant late -DSEEDMI_LATE_PROLOGUE=1
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")])
+    else:
+        build(force="--force" in sys.argv, devtools="--devtools" in sys.argv)

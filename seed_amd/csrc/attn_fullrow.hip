@@ -207,7 +207,8 @@ template <int HD, int NKP, bool CAUSAL, bool ROUND_S, bool TRV>
 int launch_attn_v(const AttnParams& p, int batch, hipStream_t stream) {
     constexpr int HDP = AttnGeom<HD>::HDP;
     constexpr int lds = (NKP * AttnGeom<HD>::KPITCH + (TRV ? NKP * AttnGeom<HD>::VRP : HDP * (NKP + 8))) * 2;
-    static bool attr_set = false;
+    static bool attr_set_dev[SEEDMI_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[seedmi_current_device()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_fullrow_kernel<HD, NKP, CAUSAL, ROUND_S, TRV>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -294,15 +294,12 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.n = nq; p.heads = heads; p.items = batch * heads; p.scale = scale;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int dev = seedmi_current_device();
+    const int n_cu = seedmi_device_cus(dev);
     const int grid = p.items < n_cu ? p.items : n_cu;
     constexpr int lds = VLDS_BYTES;
-    static bool attr_set = false;
+    static bool attr_set_dev[SEEDMI_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[dev];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "common.h"
+#include "seedmi_internal.h"
 #include "../../include/seedmi.h"
 
 static thread_local char g_err[512] = "";
@@ -21,6 +22,21 @@ int seedmi_check_launch(const char* what) {
         return SEEDMI_E_HIP;
     }
     return SEEDMI_OK;
+}
+
+int seedmi_current_device(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SEEDMI_MAX_DEVICES) dev = 0;
+    return dev;
+}
+
+int seedmi_device_cus(int dev) {
+    static int n_cu[SEEDMI_MAX_DEVICES] = {};
+    if (!n_cu[dev]) {
+        hipDeviceProp_t prop;
+        n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return n_cu[dev];
 }
 
 extern "C" int seedmi_version(void) { return SEEDMI_ABI_VERSION; }

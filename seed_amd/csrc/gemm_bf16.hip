@@ -28,6 +28,10 @@
 #ifndef SEEDMI_GEMM_PRIO
 #define SEEDMI_GEMM_PRIO 0
 #endif
+// 1: the persistent kernel issues the next tile's LDS-DMA after the epilogue's own loads have landed instead of before the epilogue
+#ifndef SEEDMI_LATE_PROLOGUE
+#define SEEDMI_LATE_PROLOGUE 0
+#endif
 
 namespace {
 
@@ -112,11 +116,17 @@ SEEDMI_DEVINL bool gelu_in_table(uint32_t h) { return ((h & 0x7fffu) - (GELU_E_M
 // inside N the 16-byte halves of the four lanes are transposed with v_permlane16_swap / v_permlane32_swap so that each store
 // instruction writes 64 contiguous bytes of a row instead of four 16-byte pieces at a 32-byte stride (whole 32-byte sectors
 // instead of half sectors: -7 % on the ViT QKV GEMM).
-template <int EPI, int MT, bool LANE4 = true>
-SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int mrow0, int nb, int li, const char* lut = nullptr) {
+struct NoHook { SEEDMI_DEVINL void operator()() const {} };
+
+// after_loads: called once, after the epilogue's up-front loads have been issued AND waited for and before its first store (the
+// persistent kernel starts the next tile's LDS-DMA there: hipcc waits vmcnt(0) for every ordinary load while LDS-DMA is in flight,
+// so DMA issued ahead of the bias / residual loads puts its own latency into the epilogue's critical path)
+template <int EPI, int MT, bool LANE4 = true, typename Hook = NoHook>
+SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int mrow0, int nb, int li, const char* lut = nullptr,
+                                 Hook after_loads = Hook()) {
     const int span0 = nb & ~63;                                   // first column of the wave's 64-column span (wave-uniform)
     const bool span_full = LANE4 && EPI != EPI_SWIGLU && (span0 + 64 <= p.N) && p.skip_epilogue == 0;
-    if (nb >= p.N) return;
+    if (nb >= p.N) { after_loads(); return; }
     const bool full = (nb + 16 <= p.N);
     float bias[16];
 #pragma unroll
@@ -131,6 +141,11 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
         } else {
             for (int i = 0; i < 16; ++i) if (nb + i < p.N) bias[i] = bf2f(p.bias[nb + i]);
         }
+    }
+    if (!(EPI == EPI_BIAS_RESIDUAL || EPI == EPI_PATCH_EMBED)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bias[i]));     // the bias has landed
+        after_loads();
     }
     // residual / pos_embed rows of ALL the lane's rows are requested up front: one exposed HBM latency per tile instead
     // of one per row (the per-row form serialised 8 round trips and cost the proj GEMM 25 %).  With 8 row groups that is 64
@@ -152,6 +167,7 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             }
         }
     }
+    if (RES) after_loads();                                        // (ragged / small-tile paths: no ordering benefit sought)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
         const int m = mrow0 + 16 * mi + li;
@@ -284,7 +300,8 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
 // B = 256 over the bias-only epilogue.  Here the residual rows are fetched in two halves of 32 registers and the first half's
 // finished rows are HELD (packed, 32 registers, while their accumulators die) until the second half's loads have been issued: every
 // load of the epilogue precedes every store, nothing spills.
-SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li) {
+template <typename Hook>
+SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li, Hook after_loads) {
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     const int span0 = nb & ~63;
     float bias[16];
@@ -355,6 +372,8 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
     for (int mi = 0; mi < 4; ++mi)
         asm volatile("" : "+v"(rr[mi][0].x), "+v"(rr[mi][0].y), "+v"(rr[mi][0].z), "+v"(rr[mi][0].w), "+v"(rr[mi][1].x), "+v"(rr[mi][1].y),
                      "+v"(rr[mi][1].z), "+v"(rr[mi][1].w));
+    __builtin_amdgcn_sched_barrier(0);
+    after_loads();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) store_row(mi, ha[mi], hc[mi]);
@@ -487,6 +506,39 @@ constexpr int KT_BYTES = 4 * HALF_BYTES;          // 64 KiB per K-tile
 #define SEEDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 
+// Segment list (tile, first K-iteration, end K-iteration) of this workgroup, written to LDS (see gemm256_kernel): the data-parallel
+// tiles of its XCD chunk, then - with a stream-K workspace - its share of the chunk's last 2..3 rounds, walked backwards.
+SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid) {
+    const int nt = p.tiles_m * p.tiles_n;
+    int n_seg = 0;
+    const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    const int cs = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
+    const int n_x = q + (xcd < r ? 1 : 0);
+    const int G = ((int)gridDim.x + 7 - xcd) >> 3;
+    int n_dp = (n_x - idx + G - 1) / G;             // data-parallel tiles cs + idx + j G < cs + n_x
+    if (n_dp < 0) n_dp = 0;
+    int sk_it = 0, sk_hi = 0, sk_tile0 = 0;         // stream-K range in K iterations over tiles sk_tile0 + i / nk
+    if (p.sk_slabs && n_x >= G) {
+        n_dp = max(n_x / G - 2, 0);                 // whole data-parallel rounds
+        sk_tile0 = cs + n_dp * G;
+        const int I = (n_x - n_dp * G) * nk;
+        sk_it = (int)(((long long)idx * I) / G);
+        sk_hi = (int)(((long long)(idx + 1) * I) / G);
+    }
+    if (n_dp > MAX_SEGS - 5) n_dp = MAX_SEGS - 5;   // (the launcher keeps nt / grid below this)
+    for (int j = tid; j < n_dp; j += 512) { segs[3 * j] = cs + idx + j * G; segs[3 * j + 1] = 0; segs[3 * j + 2] = nk; }
+    n_seg = n_dp;
+    while (sk_it < sk_hi) {                         // <= 4 segments, from the END of the range (uniform)
+        const int tl = (sk_hi - 1) / nk;
+        const int ke = sk_hi - tl * nk;
+        const int kb = max(0, ke - (sk_hi - sk_it));
+        if (tid == 0) { segs[3 * n_seg] = sk_tile0 + tl; segs[3 * n_seg + 1] = kb; segs[3 * n_seg + 2] = ke; }
+        sk_hi -= ke - kb;
+        ++n_seg;
+    }
+    return n_seg;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr bool PRIO = SEEDMI_GEMM_PRIO;
@@ -509,40 +561,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     //      STARTS from the image the previous workgroup published two tiles' time earlier (carry-in instead of zero), then
     //      runs the ordinary epilogue.  The accumulation chain of a shared tile is therefore the same k-ordered chain as
     //      an unshared one: results are bit-identical to the data-parallel walk.
-    const int nt = p.tiles_m * p.tiles_n;
     const int nk = p.K / BK;
     // The segment list (tile, first K-tile, end K-tile) of this workgroup is written to LDS once (behind the operand ring and the
     // activation table) and read back one entry per tile: the walk then costs two SGPRs of state instead of a dozen.
     int* const segs = (int*)(smem + 2 * KT_BYTES + GELU_LUT_BYTES);
     constexpr int SCRATCH_OFF = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES;
-    int n_seg = 0;
-    {
-        const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
-        const int cs = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
-        const int n_x = q + (xcd < r ? 1 : 0);
-        const int G = ((int)gridDim.x + 7 - xcd) >> 3;
-        int n_dp = (n_x - idx + G - 1) / G;             // data-parallel tiles cs + idx + j G < cs + n_x
-        if (n_dp < 0) n_dp = 0;
-        int sk_it = 0, sk_hi = 0, sk_tile0 = 0;         // stream-K range in K-tile iterations over tiles sk_tile0 + i / nk
-        if (p.sk_slabs && n_x >= G) {
-            n_dp = max(n_x / G - 2, 0);                 // whole data-parallel rounds
-            sk_tile0 = cs + n_dp * G;
-            const int I = (n_x - n_dp * G) * nk;
-            sk_it = (int)(((long long)idx * I) / G);
-            sk_hi = (int)(((long long)(idx + 1) * I) / G);
-        }
-        if (n_dp > MAX_SEGS - 5) n_dp = MAX_SEGS - 5;   // (the launcher keeps nt / grid below this)
-        for (int j = tid; j < n_dp; j += 512) { segs[3 * j] = cs + idx + j * G; segs[3 * j + 1] = 0; segs[3 * j + 2] = nk; }
-        n_seg = n_dp;
-        while (sk_it < sk_hi) {                         // <= 4 segments, from the END of the range (uniform)
-            const int tl = (sk_hi - 1) / nk;
-            const int ke = sk_hi - tl * nk;
-            const int kb = max(0, ke - (sk_hi - sk_it));
-            if (tid == 0) { segs[3 * n_seg] = sk_tile0 + tl; segs[3 * n_seg + 1] = kb; segs[3 * n_seg + 2] = ke; }
-            sk_hi -= ke - kb;
-            ++n_seg;
-        }
-    }
+    const int n_seg = build_segments(p, nk, segs, tid);
     if (n_seg == 0) return;                                            // uniform for the whole workgroup
     if (EPI == EPI_BIAS_GELU) load_gelu_lut(smem + 2 * KT_BYTES, tid, 512);   // activation table behind the operand ring
     __syncthreads();
@@ -763,10 +787,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // every LDS read of this segment is done: start the next segment's prologue loads now so that their latency (and the
     // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
     const bool more = next_seg(s_tile, s_kb, s_ke);
-    if (more) {
-        set_tile(s_tile);
-        issue_prologue(s_kb, s_ke);
-    }
+    constexpr bool late = SEEDMI_LATE_PROLOGUE != 0;
+    auto start_next = [&]() {
+        if (more) {
+            set_tile(s_tile);
+            issue_prologue(s_kb, s_ke);
+        }
+    };
+    auto hook = [&]() { if (late) start_next(); };
+    if (!late || ke < nk) start_next();
     if (ke < nk) {
         // ---- K head of a shared tile (the first stream-K segment): publish the accumulator image ([wave][4-register group][lane]
         //      x 16 B: every store instruction writes 1 KiB contiguous) write-through, then the flag.  Protocol of the CDNA guide
@@ -786,37 +815,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     } else {
         const int enb = en0 + 64 * wn + 16 * g;
         if (EPI == EPI_BIAS_RESIDUAL && p.skip_epilogue == 0 && (enb & ~63) + 64 <= p.N) {
-            gemm_epilogue_residual8(p, acc, em0 + 128 * wm, enb, li);
+            gemm_epilogue_residual8(p, acc, em0 + 128 * wm, enb, li, hook);
         } else if (p.skip_epilogue != 1) {
-            gemm_epilogue<EPI, 8>(p, acc, em0 + 128 * wm, enb, li, lut);
-        } else if (acc[0][0][0] == 123.456f) {
-            p.C[0] = 0;                                     // keep the accumulators alive
+            gemm_epilogue<EPI, 8, true>(p, acc, em0 + 128 * wm, enb, li, lut, hook);
+        } else {
+            hook();
+            if (acc[0][0][0] == 123.456f) p.C[0] = 0;       // keep the accumulators alive
         }
     }
     if (!more) break;
     }
 }
 
+
 #ifdef SEEDMI_DEVTOOLS
 #include "gemm_devtools.inc"
 #endif
 
-// per-device launch state (function attributes are per device; so is the CU count)
-constexpr int MAX_DEVICES = 64;
-struct DeviceInfo { int n_cu = 0; };
-DeviceInfo g_dev[MAX_DEVICES];
-int current_device() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
-    return dev;
-}
-int device_cus(int dev) {
-    if (!g_dev[dev].n_cu) {
-        hipDeviceProp_t prop;
-        g_dev[dev].n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
-    return g_dev[dev].n_cu;
-}
+// per-device launch state (function attributes are per device; so is the CU count): seedmi_internal.h
+constexpr int MAX_DEVICES = SEEDMI_MAX_DEVICES;
+int current_device() { return seedmi_current_device(); }
+int device_cus(int dev) { return seedmi_device_cus(dev); }
 
 constexpr size_t SK_SLAB_BYTES = (size_t)B2 * B2 * 4;       // one fp32 accumulator image per workgroup
 constexpr size_t SK_FLAGS_BYTES = 4096;                      // one flag word per workgroup (<= 1024 CUs)
@@ -851,6 +870,10 @@ int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_b
     return seedmi_check_launch("gemm256");
 }
 
+#ifdef SEEDMI_DEVTOOLS
+#include "gemm_devtools_k.inc"
+#endif
+
 template <int EPI>
 int launch_gemm128(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = 2 * STAGE_BYTES + (EPI == EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
@@ -873,6 +896,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
     const bool big = p.M >= 1024 && p.N >= 256 && tiles256 >= g_gemm_min_tiles;
     const int variant = g_gemm_variant;
 #ifdef SEEDMI_DEVTOOLS
+    if (variant == 257 && EPI != EPI_SWIGLU && EPI != EPI_PATCH_EMBED) return launch_gemm256k<EPI>(p, s, sk_ws, sk_ws_bytes);
     if (variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
     if (variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
 #endif
@@ -884,7 +908,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
 
 extern "C" int seedmi_set_option(const char* key, int value) {
 #ifdef SEEDMI_DEVTOOLS
-    const bool dev_variant = value == 232 || value == 255;
+    const bool dev_variant = value == 232 || value == 255 || value == 257;
 #else
     const bool dev_variant = false;
 #endif

@@ -224,12 +224,7 @@ int launch_skinny_nw(const SkinnyParams& p, hipStream_t s) {
     // is empty, so R is chosen for the fullest rounds: R = 1 runs two workgroups per CU (116 VGPRs), R >= 2 one; ties go to the
     // larger R (each activation fragment is reused R times).  8B QKV: 768 tiles -> R = 3 = exactly one workgroup per CU (+19 %).
     const int tiles = (p.N + 15) / 16;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = seedmi_device_cus(seedmi_current_device());
     int best_r = 1;
     if (g_skinny_r != 0) {
         best_r = g_skinny_r;
@@ -937,7 +932,8 @@ extern "C" int seedmi_llama_decode_attention_bf16(const void* qkv, int ldqkv, co
         seedmi_set_error("seedmi_llama_decode_attention_bf16: kv_len %d too long for the decode kernel", lds_len);
         return SEEDMI_E_SHAPE;
     }
-    static bool attr_set = false;
+    static bool attr_set_dev[SEEDMI_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[seedmi_current_device()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_decode_rope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
@@ -978,7 +974,8 @@ extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k
             seedmi_set_error("seedmi_llama_attention_bf16: kv_len %d too long for the decode kernel", kv_len);
             return SEEDMI_E_SHAPE;
         }
-        static bool attr_set = false;
+        static bool attr_set_dev[SEEDMI_MAX_DEVICES] = {};
+        bool& attr_set = attr_set_dev[seedmi_current_device()];
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr_set = true;

@@ -25,3 +25,8 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
                              int batch, int heads, int head_dim, int nq, int nk, float scale, int causal, int round_scores,
                              void* stream);
 int seedmi_attn_vit_set(int v);
+
+// per-device launch state (function attributes and the CU count belong to a device, not to the process): capi.hip
+#define SEEDMI_MAX_DEVICES 64
+int seedmi_current_device(void);          // hipGetDevice, clamped to [0, SEEDMI_MAX_DEVICES)
+int seedmi_device_cus(int dev);           // multiProcessorCount of that device (cached)

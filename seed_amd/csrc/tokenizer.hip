@@ -11,6 +11,7 @@
 // HBM-bound LayerNorm / attention kernels; the second stream's workgroups fill those holes.  Nothing is allocated
 // per call (streams/events are created once), there is no host sync, and fork/join by events is graph-capturable.
 #include "common.h"
+#include "seedmi_internal.h"
 #include "../../include/seedmi.h"
 
 namespace {
@@ -175,23 +176,36 @@ constexpr int SPLIT_MIN_BATCH = 32;      // below this the kernels are too small
 int g_tok_streams = 2;                    // seedmi_set_option("tokenize_streams", 1|2)
 
 constexpr int MAX_PARTS = 4;
+// side streams and fork/join events of the sub-batch overlap: one set per (thread, device), created on first use and kept for the
+// life of the thread (a device change no longer leaks the previous device's objects: each device keeps its own slot)
 struct ForkJoin {
     hipStream_t side[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
-    int device = -1;
 };
-thread_local ForkJoin g_fj;
-
-int ensure_forkjoin() {
-    int dev = 0;
-    HIPCK(hipGetDevice(&dev));
-    if (g_fj.fork && g_fj.device == dev) return SEEDMI_OK;
-    HIPCK(hipEventCreateWithFlags(&g_fj.fork, hipEventDisableTiming));
-    for (int i = 0; i < MAX_PARTS - 1; ++i) {
-        HIPCK(hipStreamCreateWithFlags(&g_fj.side[i], hipStreamNonBlocking));
-        HIPCK(hipEventCreateWithFlags(&g_fj.join[i], hipEventDisableTiming));
+struct ForkJoinSet {
+    ForkJoin dev[SEEDMI_MAX_DEVICES];
+    ~ForkJoinSet() {
+        for (ForkJoin& f : dev) {
+            if (!f.fork) continue;
+            (void)hipEventDestroy(f.fork);
+            for (int i = 0; i < MAX_PARTS - 1; ++i) {
+                (void)hipEventDestroy(f.join[i]);
+                (void)hipStreamDestroy(f.side[i]);
+            }
+        }
     }
-    g_fj.device = dev;
+};
+thread_local ForkJoinSet g_fj_set;
+
+int ensure_forkjoin(ForkJoin** out) {
+    ForkJoin& f = g_fj_set.dev[seedmi_current_device()];
+    *out = &f;
+    if (f.fork) return SEEDMI_OK;
+    HIPCK(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+    for (int i = 0; i < MAX_PARTS - 1; ++i) {
+        HIPCK(hipStreamCreateWithFlags(&f.side[i], hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming));
+    }
     return SEEDMI_OK;
 }
 
@@ -269,12 +283,13 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
         p.s = (hipStream_t)stream;
         b_begin += p.B;
     }
+    ForkJoin* fj = nullptr;
     if (split) {
-        CK(ensure_forkjoin());
-        HIPCK(hipEventRecord(g_fj.fork, (hipStream_t)stream));
+        CK(ensure_forkjoin(&fj));
+        HIPCK(hipEventRecord(fj->fork, (hipStream_t)stream));
         for (int i = 1; i < nparts; ++i) {
-            parts[i].s = g_fj.side[i - 1];
-            HIPCK(hipStreamWaitEvent(g_fj.side[i - 1], g_fj.fork, 0));
+            parts[i].s = fj->side[i - 1];
+            HIPCK(hipStreamWaitEvent(fj->side[i - 1], fj->fork, 0));
         }
     }
     if (g_tok_streamk)
@@ -284,8 +299,8 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
     for (int ph = 0; ph < np; ++ph)
         for (int i = 0; i < nparts; ++i) CK(run_phase(parts[i], ph));
     for (int i = 1; i < nparts; ++i) {
-        HIPCK(hipEventRecord(g_fj.join[i - 1], g_fj.side[i - 1]));
-        HIPCK(hipStreamWaitEvent((hipStream_t)stream, g_fj.join[i - 1], 0));
+        HIPCK(hipEventRecord(fj->join[i - 1], fj->side[i - 1]));
+        HIPCK(hipStreamWaitEvent((hipStream_t)stream, fj->join[i - 1], 0));
     }
     return SEEDMI_OK;
 }

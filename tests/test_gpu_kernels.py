@@ -176,7 +176,7 @@ def test_gemm_gelu_epilogue_is_torch_gelu_bit_for_bit(lib, gemm_variant):
 @pytest.mark.parametrize("M,N,K,epi", [(257 * 256, 1408, 1408, "residual"), (257 * 256 + 77, 1408, 768, "bias"),
                                         (257 * 128, 4224, 1408, "bias"), (257 * 64, 6144, 1408, "gelu"),
                                         (256 * 300, 768, 64, "bias")])
-def test_gemm_streamk_is_bit_identical_to_data_parallel(lib, M, N, K, epi):
+def test_gemm_streamk_is_bit_identical_to_data_parallel(lib, M, N, K, epi, variant=256):
     """seedmi_gemm_bf16_ws: the last partial round of tiles is cut along K (stream-K); a shared tile's K tail CONTINUES the fp32
     accumulator image its partner published, so every output equals the data-parallel launch bit for bit - and both match the
     fp32 restatement.  Repeated launches reuse the workspace (epoch flags), as the tokenizer does."""
@@ -188,6 +188,7 @@ def test_gemm_streamk_is_bit_identical_to_data_parallel(lib, M, N, K, epi):
     code = {"residual": L.EPI_BIAS_RESIDUAL, "bias": L.EPI_BIAS, "gelu": L.EPI_BIAS_GELU}[epi]
     ws = torch.empty(lib.seedmi_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
     ws[:4096].zero_()
+    L.check(lib.seedmi_set_option(b"gemm", variant), "set_option")
     C0 = run_gemm(lib, A, W, bias, res, code)
     for rep in range(3):
         C1 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
@@ -199,7 +200,8 @@ def test_gemm_streamk_is_bit_identical_to_data_parallel(lib, M, N, K, epi):
     rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])          # fp32 check on the first / last tiles' rows
     acc = A[rows].float() @ W.float().t() + bias.float()
     want = {"bias": r(acc), "gelu": r(gelu(r(acc))), "residual": r(r(acc) + (res[rows].float() if res is not None else 0))}[epi]
-    assert_close_bf16(C0[rows], want, f"gemm_streamk {M}x{N}x{K} {epi}", frac=0.998)
+    lib.seedmi_set_option(b"gemm", 0)
+    assert_close_bf16(C0[rows], want, f"gemm_streamk[{variant}] {M}x{N}x{K} {epi}", frac=0.998)
 
 
 def test_gemm_residual_inplace(lib, gemm_variant):
