@@ -123,6 +123,8 @@ int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, c
                           int past_len, const void* past_len_dev, int max_pos, void* stream);
 /* *counter += delta on the stream (the decode graph advances its device-resident cache length with it). */
 int seedmi_add_i32(void* counter_dev, int delta, void* stream);
+/* dst[i] += inc[i], i < n (the continuous-batching step advances the cache length of every ACTIVE slot with it). */
+int seedmi_add_i32_vec(void* dst_i32, const void* inc_i32, int n, void* stream);
 /* Decode step (T == 1) of LlamaAttention.forward with apply_rotary_pos_emb, the cache append and the attention in one launch
  * (llama_xformer.py:147-168, 228-256): qkv [B, 3*H*hd] (q|k|v) un-rotated; the new key/value row is written to the caches at
  * past_len (or *past_len_dev) and attended to together with the cached rows.  pos_ids_i64 [B] may be NULL (position = past). */
@@ -312,6 +314,12 @@ int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const void* ids_i64
 int seedmi_llama_forward_io(const seedmi_llama_weights_t* w, const void* ids_i64, const void* inputs_embeds, const void* pos_i64,
                             int batch, int T, int past_len, const void* past_len_dev, int last_only, void* logits, int ldl,
                             void* hidden_states, void* workspace, size_t workspace_bytes, void* stream);
+/* One decode step over `batch` independent slots of the static KV cache, slot b at its own cache length lens_i32[b] (device int32):
+ * the step a continuous-batching serving loop replays (gradio_demo/seed_llama_flask.py:166-174 generates one request at a time; the
+ * survey's f4 row asks for batching on top).  tok_i64 [batch] are the slots' current tokens; logits bf16 [batch, ldl] (last
+ * position of every slot).  Rows are independent: an idle slot (length 0, any token) costs its share of the weight stream only. */
+int seedmi_llama_decode_slots(const seedmi_llama_weights_t* w, const void* tok_i64, const void* lens_i32, int batch, void* logits,
+                              int ldl, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -357,10 +357,11 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
                                                                bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                                bf16_t* __restrict__ out, int ldo, int H, int tmax, int past_arg,
                                                                float scale, int out_packed, int lds_len,
-                                                               const int* __restrict__ past_dev, int max_pos) {
+                                                               const int* __restrict__ past_dev, int max_pos, int past_stride) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     // (a graph replayed past the cache capacity keeps rewriting the last row instead of leaving the allocation)
-    const int past = past_dev ? min(*past_dev, tmax - 1) : past_arg;
+    // past_stride 0: one cache length for the whole batch; 1: one per row (continuous batching: every slot at its own position)
+    const int past = past_dev ? min(past_dev[(blockIdx.x / H) * past_stride], tmax - 1) : past_arg;
     const int kv_len = past + 1;
     float* sc = dsm;
     float* part = dsm + lds_len;
@@ -403,23 +404,36 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
             *(uint4*)(vb + (size_t)past * DEC_HD + 8 * c) = vnew;
         }
     }
-    // scores: cached keys from HBM, the new key (j == past) from registers
+    // scores: cached keys from HBM, the new key (j == past) from registers.  The key rows of a thread (j = ks, ks + 16, ...) are
+    // requested DU at a time before any of them is used: one exposed memory latency per DU rows instead of one per row (at ctx 123 the
+    // un-batched loop was 8 dependent round trips for QK^T and 8 more for PV - most of this kernel's 20 us)
+    constexpr int DU = 8;
     float lmax = -INFINITY;
-    for (int j = ks; j < kv_len; j += 16) {
-        float d = 0.f;
-        if (j < past) {
-            const uint4 u = *(const uint4*)(kb + (size_t)j * DEC_HD + 8 * c);
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    for (int j0 = ks; j0 < kv_len; j0 += 16 * DU) {
+        uint4 kr[DU];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) d += qv[2 * i] * lo_bf(w[i]) + qv[2 * i + 1] * hi_bf(w[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d += qv[2 * i] * kn[2 * i] + qv[2 * i + 1] * kn[2 * i + 1];
+        for (int u = 0; u < DU; ++u) {
+            const int j = j0 + 16 * u;
+            if (j < past) kr[u] = *(const uint4*)(kb + (size_t)j * DEC_HD + 8 * c);
         }
-        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-        d *= scale;
-        if (c == 0) sc[j] = d;
-        lmax = fmaxf(lmax, d);
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int j = j0 + 16 * u;
+            if (j >= kv_len) break;
+            float d = 0.f;
+            if (j < past) {
+                const uint32_t w[4] = {kr[u].x, kr[u].y, kr[u].z, kr[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d += qv[2 * i] * lo_bf(w[i]) + qv[2 * i + 1] * hi_bf(w[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d += qv[2 * i] * kn[2 * i] + qv[2 * i + 1] * kn[2 * i + 1];
+            }
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+            d *= scale;
+            if (c == 0) sc[j] = d;
+            lmax = fmaxf(lmax, d);
+        }
     }
     lmax = wave_max(lmax);
     if (lane == 0) wred[wave] = lmax;
@@ -437,12 +451,23 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
     __syncthreads();
     const float inv = 1.0f / (wred[0] + wred[1] + wred[2] + wred[3]);
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j = ks; j < kv_len; j += 16) {
-        const float pj = rbf(sc[j] * inv);
-        const uint4 u = (j < past) ? *(const uint4*)(vb + (size_t)j * DEC_HD + 8 * c) : vnew;
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    for (int j0 = ks; j0 < kv_len; j0 += 16 * DU) {
+        uint4 vr[DU];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { o[2 * i] += pj * lo_bf(w[i]); o[2 * i + 1] += pj * hi_bf(w[i]); }
+        for (int u = 0; u < DU; ++u) {
+            const int j = j0 + 16 * u;
+            vr[u] = vnew;
+            if (j < past) vr[u] = *(const uint4*)(vb + (size_t)j * DEC_HD + 8 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int j = j0 + 16 * u;
+            if (j >= kv_len) break;
+            const float pj = rbf(sc[j] * inv);
+            const uint32_t w[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[2 * i] += pj * lo_bf(w[i]); o[2 * i + 1] += pj * hi_bf(w[i]); }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) part[ks * DEC_HD + 8 * c + i] = o[i];
@@ -916,10 +941,21 @@ extern "C" int seedmi_pack_skinny_weights(const void* W, int ldw, int N, int K, 
     return seedmi_check_launch("pack_skinny_weights");
 }
 
+static int decode_attention_launch(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t, const void* sin_t,
+                                   void* k_cache, void* v_cache, void* out, int ldo, int B, int H, int hd, int tmax, int past_len,
+                                   float scale, int out_packed, const void* past_len_dev, int past_stride, int max_pos, void* stream);
+
 extern "C" int seedmi_llama_decode_attention_bf16(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t,
                                                   const void* sin_t, void* k_cache, void* v_cache, void* out, int ldo, int B,
                                                   int H, int hd, int tmax, int past_len, float scale, int out_packed,
                                                   const void* past_len_dev, int max_pos, void* stream) {
+    return decode_attention_launch(qkv, ldqkv, pos_ids_i64, cos_t, sin_t, k_cache, v_cache, out, ldo, B, H, hd, tmax, past_len, scale,
+                                   out_packed, past_len_dev, 0, max_pos, stream);
+}
+
+static int decode_attention_launch(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t, const void* sin_t,
+                                   void* k_cache, void* v_cache, void* out, int ldo, int B, int H, int hd, int tmax, int past_len,
+                                   float scale, int out_packed, const void* past_len_dev, int past_stride, int max_pos, void* stream) {
     if (hd != DEC_HD || B <= 0 || H <= 0 || past_len < 0 || past_len + 1 > tmax || (ldqkv % 8) || max_pos <= 0 ||
         (((uintptr_t)qkv | (uintptr_t)cos_t | (uintptr_t)sin_t | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)) {
         seedmi_set_error("seedmi_llama_decode_attention_bf16: B=%d H=%d hd=%d (must be 128) past=%d tmax=%d ldqkv=%d", B, H, hd,
@@ -941,7 +977,7 @@ extern "C" int seedmi_llama_decode_attention_bf16(const void* qkv, int ldqkv, co
     hipLaunchKernelGGL(attn_decode_rope_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv,
                        (const long long*)pos_ids_i64, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
                        (bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, past_len, scale, out_packed, lds_len,
-                       (const int*)past_len_dev, max_pos);
+                       (const int*)past_len_dev, max_pos, past_stride);
     return seedmi_check_launch("attn_decode_rope");
 }
 
@@ -1016,10 +1052,34 @@ extern "C" int seedmi_llama_forward_ex(const seedmi_llama_weights_t* w, const vo
                                    workspace, workspace_bytes, stream);
 }
 
+static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i64, const void* inputs_embeds, const void* pos_i64,
+                              int batch, int T, int past_len, const void* past_len_dev, int past_stride, int last_only,
+                              void* logits, int ldl, void* hidden_states, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int seedmi_llama_forward_io(const seedmi_llama_weights_t* w, const void* ids_i64, const void* inputs_embeds,
                                        const void* pos_i64, int batch, int T, int past_len, const void* past_len_dev,
                                        int last_only, void* logits, int ldl, void* hidden_states, void* workspace,
                                        size_t workspace_bytes, void* stream) {
+    return llama_forward_impl(w, ids_i64, inputs_embeds, pos_i64, batch, T, past_len, past_len_dev, 0, last_only, logits, ldl,
+                              hidden_states, workspace, workspace_bytes, stream);
+}
+
+// One decode step of `batch` independent SLOTS, each at its own cache length lens_i32[b] (device): the continuous-batching step.
+// Row b appends its token at position lens[b] of its cache row and attends over lens[b] + 1 keys; everything else is the ordinary
+// single-token step (every kernel of it is row-independent).  Graph-replayable: nothing but device memory changes between steps.
+extern "C" int seedmi_llama_decode_slots(const seedmi_llama_weights_t* w, const void* tok_i64, const void* lens_i32, int batch,
+                                         void* logits, int ldl, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!lens_i32 || !g_decode_fused) {
+        seedmi_set_error("seedmi_llama_decode_slots: needs per-slot lengths and the fused decode attention");
+        return SEEDMI_E_SHAPE;
+    }
+    return llama_forward_impl(w, tok_i64, nullptr, nullptr, batch, 1, w ? w->tmax - 1 : 0, lens_i32, 1, 1, logits, ldl, nullptr,
+                              workspace, workspace_bytes, stream);
+}
+
+static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i64, const void* inputs_embeds, const void* pos_i64,
+                              int batch, int T, int past_len, const void* past_len_dev, int past_stride, int last_only,
+                              void* logits, int ldl, void* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
     if (!w || (!ids_i64 && !inputs_embeds) || (ids_i64 && inputs_embeds) || (!pos_i64 && !past_len_dev) || !logits || batch <= 0 ||
         T <= 0) {
         seedmi_set_error("seedmi_llama_forward: null argument, both/neither of ids and inputs_embeds, or bad batch/T");
@@ -1088,9 +1148,8 @@ extern "C" int seedmi_llama_forward_io(const seedmi_llama_weights_t* w, const vo
         }
         if (T == 1 && g_decode_fused) {
             // RoPE + cache append + attention in one launch (bit-identical to the two-kernel form below)
-            CK(seedmi_llama_decode_attention_bf16(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, L.k_cache,
-                                                  L.v_cache, t.att, h, batch, H, hd, w->tmax, past_len, scale, pk, past_len_dev,
-                                                  w->max_pos, stream));
+            CK(decode_attention_launch(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, L.k_cache, L.v_cache, t.att, h,
+                                       batch, H, hd, w->tmax, past_len, scale, pk, past_len_dev, past_stride, w->max_pos, stream));
         } else {
             CK(seedmi_rope_kv_append(t.qkv, 3 * h, past_len_dev ? nullptr : pos_i64, w->cos_t, w->sin_t, t.q, h, L.k_cache,
                                      L.v_cache, batch, T, H, hd, w->tmax, past_len, past_len_dev, w->max_pos, stream));

@@ -236,6 +236,10 @@ __global__ void rope_kv_append_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
 }
 
 __global__ void add_i32_kernel(int* p, int delta) { *p += delta; }
+__global__ void add_i32_vec_kernel(int* __restrict__ p, const int* __restrict__ inc, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += inc[i];
+}
 
 int grid_for(long long total, int block) {
     long long g = (total + block - 1) / block;
@@ -329,6 +333,15 @@ extern "C" int seedmi_fill_rows(void* dst, int ld, int group_rows, int r0, int n
 extern "C" int seedmi_add_i32(void* counter_dev, int delta, void* stream) {
     hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)counter_dev, delta);
     return seedmi_check_launch("add_i32");
+}
+
+extern "C" int seedmi_add_i32_vec(void* dst_i32, const void* inc_i32, int n, void* stream) {
+    if (!dst_i32 || !inc_i32 || n <= 0) {
+        seedmi_set_error("seedmi_add_i32_vec: bad arguments");
+        return SEEDMI_E_SHAPE;
+    }
+    hipLaunchKernelGGL(add_i32_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int*)dst_i32, (const int*)inc_i32, n);
+    return seedmi_check_launch("add_i32_vec");
 }
 
 extern "C" int seedmi_embed_rows(const void* ids_i64, const void* table, int ldt, void* out, int ldo, int n, int cols,

@@ -79,6 +79,8 @@ SIGNATURES = {
     "seedmi_embed_rows": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "seedmi_add_i32": (_i, [_vp, _i, _vp]),
+    "seedmi_add_i32_vec": (_i, [_vp, _vp, _i, _vp]),
+    "seedmi_llama_decode_slots": (_i, [C.POINTER(LlamaWeights), _vp, _vp, _i, _vp, _i, _vp, C.c_size_t, _vp]),
     "seedmi_llama_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp, _vp]),
     "seedmi_llama_decode_attention_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp,
                                                 _i, _vp]),

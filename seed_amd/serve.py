@@ -6,8 +6,11 @@ Same JSON keys, defaults, assertion and ``error_msg`` texts as the reference han
 * raw images go PIL -> ``DevicePreprocessor`` (bit-exact with the reference's transform) -> ``TokenizerEngine.encode``;
 * the prompt is spliced by id arithmetic (``32000 + code`` between ``<img>`` / ``</img>``) instead of formatting
   ``<img_XXXXX>`` strings and re-tokenising them (:149-164);
-* ``model.generate(do_sample=True, top_p, temperature)`` (:166-174) is ``LlamaEngine.sample_decode_graph``: prefill, then one
-  captured step (forward + top-p draw) replayed on the device; the output is cut at the first EOS afterwards;
+* ``model.generate(do_sample=True, top_p, temperature)`` (:166-174) runs on the continuous-batching loop of seed_amd/batching.py:
+  the request is prefilled into a free slot of the static KV cache and decoded together with whatever else is in flight by a
+  hipGraph-captured step (forward over all slots + top-p draw + bookkeeping) that is captured ONCE per sampling configuration and
+  replayed in chunks; a request stops at its first EOS (kept, like generate()) or at the context limit, whichever comes first.
+  ``handle_many`` serves several requests concurrently (the reference's Flask dev server handles one at a time);
 * generated image spans are turned into unCLIP embeds on the device (``seedmi_detokenize``); rendering pixels needs the
   diffusers pipeline, which is not part of this library: pass ``image_renderer`` (embeds -> PIL.Image) to get base64 PNGs,
   otherwise the slot stays '' as it does in the reference when decoding fails.
@@ -47,7 +50,7 @@ class GenerateService:
     def __init__(self, text_tokenizer, encode_images: Callable[[torch.Tensor], torch.Tensor], llama_engine,
                  preprocess: Callable, boi_token_id: int = IMAGE_ID_SHIFT + NUM_IMG_CODES,
                  eoi_token_id: int = IMAGE_ID_SHIFT + NUM_IMG_CODES + 1, codebook_entry: Optional[Callable] = None,
-                 image_renderer: Optional[Callable] = None, device="cuda"):
+                 image_renderer: Optional[Callable] = None, device="cuda", batcher_factory: Optional[Callable] = None):
         self.tok = text_tokenizer
         self.encode_images = encode_images          # [B,3,S,S] device tensor -> int64 [B,32]
         self.llm = llama_engine
@@ -57,6 +60,23 @@ class GenerateService:
         self.image_renderer = image_renderer        # embeds [1,D] -> PIL.Image (the diffusers pipeline, external)
         self.image_id_shift = IMAGE_ID_SHIFT
         self.device = device
+        self._batchers = {}                         # (top_p, temperature) -> ContinuousBatcher (the captured step bakes them in)
+        self.decode_chunk = 16
+        self._batcher_factory = batcher_factory     # (top_p, temperature) -> object with submit(ids, max_new) / run() (tests)
+
+    def _batcher(self, top_p: float, temperature: float):
+        if self._batcher_factory is None:
+            from .batching import ContinuousBatcher
+        if temperature is None or temperature <= 0.0 or top_p is None or top_p <= 0.0:
+            top_p, temperature = 0.0, 1.0             # degenerate sampling requests are greedy (temperature -> 0 limit)
+        key = (float(top_p), float(temperature))
+        if key not in self._batchers:
+            if self._batcher_factory is not None:
+                self._batchers[key] = self._batcher_factory(*key)
+            else:
+                self._batchers[key] = ContinuousBatcher(self.llm, chunk=self.decode_chunk, top_p=key[0], temperature=key[1],
+                                                        eos_token_id=self.tok.eos_token_id)
+        return self._batchers[key]
 
     # ---- seed_llama_flask.py:96-147: request fields, mixed raw / pre-tokenised images
     def _image_ids(self, image_list) -> torch.Tensor:
@@ -92,7 +112,7 @@ class GenerateService:
             ids.append(self.boi_token_id)
         return ids
 
-    def handle(self, request_info: dict) -> dict:
+    def _parse_request(self, request_info: dict):
         text_list = request_info['text'].split(IMG_FLAG)
         image_list = request_info['images']
         temperature = request_info.get('temperature', 0.7)
@@ -103,18 +123,31 @@ class GenerateService:
         assert len(text_list) == len(image_list) + 1
         if num_beams != 1:
             raise ValueError("num_beams > 1 is not supported by the on-device sampler (the reference demo always sends 1)")
-
         images_ids = self._image_ids(image_list) if len(image_list) > 0 else None
         images_ids_list = images_ids.tolist() if images_ids is not None else []
         input_ids = self.build_prompt(text_list, images_ids, force_boi)
-        prompt = torch.tensor([input_ids], dtype=torch.int64, device=self.device)
+        return dict(input_ids=input_ids, images_ids_list=images_ids_list, force_boi=force_boi, top_p=top_p, temperature=temperature,
+                    max_new_tokens=max_new_tokens)
 
-        generate_ids = self.llm.sample_decode_graph(prompt, max_new_tokens, top_p=top_p, temperature=temperature)[0].cpu()
-        eos = torch.where(generate_ids == self.tok.eos_token_id)[0]
-        if len(eos) > 0:                                               # generate() stops at EOS (the EOS token itself is kept)
-            generate_ids = generate_ids[:int(eos[0]) + 1]
-        if force_boi:                                                  # :177-178 the forced <img> counts as generated
-            generate_ids = torch.cat((prompt[0, -1:].cpu(), generate_ids))
+    def handle(self, request_info: dict) -> dict:
+        return self.handle_many([request_info])[0]
+
+    def handle_many(self, requests: List[dict]) -> List[dict]:
+        """Serve several /generate requests concurrently: requests with the same sampling configuration share one decode loop."""
+        parsed = [self._parse_request(r) for r in requests]
+        tickets = []
+        for q in parsed:
+            cb = self._batcher(q['top_p'], q['temperature'])
+            tickets.append((cb, cb.submit(q['input_ids'], q['max_new_tokens'])))
+        results = {}
+        for cb in {id(cb): cb for cb, _ in tickets}.values():
+            results[id(cb)] = cb.run()
+        return [self._finish(q, torch.tensor(results[id(cb)][rid], dtype=torch.int64)) for q, (cb, rid) in zip(parsed, tickets)]
+
+    def _finish(self, q: dict, generate_ids: torch.Tensor) -> dict:
+        images_ids_list = q['images_ids_list']
+        if q['force_boi']:                                              # :177-178 the forced <img> counts as generated
+            generate_ids = torch.cat((torch.tensor([self.boi_token_id], dtype=torch.int64), generate_ids))
 
         boi_indices = torch.where(generate_ids == self.boi_token_id)[0].tolist()
         eoi_indices = torch.where(generate_ids == self.eoi_token_id)[0].tolist()

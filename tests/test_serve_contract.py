@@ -28,14 +28,34 @@ class CharTokenizer:
 
 
 class ScriptedLLM:
+    """Stands in for the decode loop (seed_amd.batching.ContinuousBatcher's submit / run protocol): replays a fixed token script and
+    stops at EOS or the budget, like the real loop."""
+
     def __init__(self, script):
         self.script, self.calls = script, []
 
-    def sample_decode_graph(self, prompt, n_new, top_p=0.5, temperature=1.0, generator=None):
-        self.calls.append(dict(prompt=prompt.clone(), n_new=n_new, top_p=top_p, temperature=temperature))
-        out = torch.full((1, n_new), 2, dtype=torch.int64)
-        out[0, :len(self.script)] = torch.tensor(self.script)
-        return out
+    def batcher(self, top_p, temperature):
+        llm = self
+
+        class B:
+            def __init__(self):
+                self.q = []
+
+            def submit(self, ids, max_new):
+                llm.calls.append(dict(prompt=torch.tensor([list(ids)]), n_new=max_new, top_p=top_p, temperature=temperature))
+                self.q.append(max_new)
+                return len(self.q) - 1
+
+            def run(self):
+                out = {}
+                for rid, n in enumerate(self.q):
+                    toks = (list(llm.script) + [2] * n)[:n]
+                    if 2 in toks:
+                        toks = toks[:toks.index(2) + 1]
+                    out[rid] = toks
+                self.q = []
+                return out
+        return B()
 
 
 def _png_b64(h=20, w=30):
@@ -48,7 +68,8 @@ def _png_b64(h=20, w=30):
 def _service(script, **kw):
     enc = lambda batch: torch.arange(32).repeat(batch.shape[0], 1) + 100          # "tokenizer": ids 100..131 per image
     pre = lambda pil: torch.zeros(3, 224, 224)
-    return serve.GenerateService(CharTokenizer(), enc, ScriptedLLM(script), pre, device="cpu", **kw)
+    llm = ScriptedLLM(script)
+    return serve.GenerateService(CharTokenizer(), enc, llm, pre, device="cpu", batcher_factory=llm.batcher, **kw)
 
 
 def test_prompt_is_spliced_by_id_arithmetic_and_defaults_match_the_reference():
@@ -117,7 +138,7 @@ def test_generate_end_to_end_on_device_engines():
     tcfg = C.TINY
     teng = TokenizerEngine(make_tokenizer_state_dict(tcfg, seed=0), tcfg)
     lcfg = dataclasses.replace(C.LLAMA_TINY, vocab=40194)
-    leng = LlamaEngine(make_llama_state_dict(lcfg, seed=1), lcfg, device="cuda", batch_cap=1, tmax=256)
+    leng = LlamaEngine(make_llama_state_dict(lcfg, seed=1), lcfg, device="cuda", batch_cap=4, tmax=256)
     pre = DevicePreprocessor(tcfg.img_size, interpolation=BILINEAR, keep_ratio=False)
     svc = serve.GenerateService(CharTokenizer(), teng.encode, leng, pre)
     out = svc.handle({'text': 'look<image>what is it?', 'images': [_png_b64(40, 50)], 'max_new_tokens': 24, 'top_p': 0.5})
@@ -125,3 +146,9 @@ def test_generate_end_to_end_on_device_engines():
     assert len(out['images_ids']) >= 1 and len(out['images_ids'][0]) == 32
     assert all(0 <= c < tcfg.n_embed for c in out['images_ids'][0])
     assert isinstance(out['text'], str)
+    # several requests at once share the decode loop; greedy replies (top_p 0 / temperature 0) do not depend on the company they keep
+    reqs = [{'text': 'a' * (3 + i), 'images': [], 'max_new_tokens': 6 + i, 'top_p': 0.0} for i in range(3)]
+    together = svc.handle_many(reqs)
+    alone = [svc.handle(r) for r in reqs]
+    assert [o['text'] for o in together] == [o['text'] for o in alone]
+    assert svc.handle({'text': 'aaa', 'images': [], 'max_new_tokens': 6, 'temperature': 0.0})['text'] == alone[0]['text']
