@@ -49,7 +49,8 @@ int seedmi_check_device(void);
  * defaults).  Keys (value): "gemm" (0 automatic | 128 | 256), "gemm_persist" (0|1), "gemm_streamk" (0|1: stream-K tail when a
  * workspace is passed), "gemm_group_m" (1..64 m-tiles per L2 tile group), "gemm_min_tiles" (256x256 kernel only at or above this
  * many tiles), "tokenize_streams" (1..4 concurrent sub-batches inside seedmi_tokenize), "tokenize_streamk" (0|1: stream-K
- * tail for the tokenizer's big GEMMs, default 0), "skinny_nt" / "skinny_waves" / "skinny_rows"
+ * tail for the tokenizer's big GEMMs, default 0), "tokenize_lnfold" (0|1: LayerNorm folded into qkv / fc1 when the weights carry
+ * the folded copies, default 1), "skinny_nt" / "skinny_waves" / "skinny_rows"
  * (decode GEMM), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
  * (attention kernel selection).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
@@ -77,6 +78,30 @@ int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* W,
  * tile shared by two workgroups is summed in fp32 from one published partial - results equal the plain call up to that one
  * re-association of the fp32 sum.  workspace == NULL is exactly seedmi_gemm_bf16. */
 size_t seedmi_gemm_workspace_bytes(void);
+/* LayerNorm folded into the two GEMMs around it (eva_vit.py:199-202: norm1 -> attn.qkv, norm2 -> mlp.fc1).
+ * Consumer (BIAS / BIAS_GELU, N % 64 == 0, ln_stats != NULL): A holds the UN-normalised rows x, W holds half(weight * gamma); ln_stats
+ * [M + (M & 1)][2] fp32 = (mean, rstd) of every row of x (an even number of rows must be readable: they are fetched in pairs), ln_colsum [N]
+ * fp32 = sum_k W[n][k], bias_f32 [N] fp32 = bias_n + sum_k beta_k weight[n][k], both 16-byte aligned; the epilogue forms
+ * rstd * (acc - mean * colsum) + bias_f32 = LayerNorm(x) weight^T + bias with one rounding to half (`bias` is ignored).
+ * Producer (BIAS_RESIDUAL, N % 64 == 0, stats_out != NULL): stats_out [N / 64][stats_ld >= M][2] fp32 (span-major planes) receives, per
+ * 64-column span and row, (sum, sum of squares) of the half outputs; seedmi_layernorm_stats_finalize reduces them to (mean, rstd).
+ * Both may be NULL (= seedmi_gemm_bf16_ws). */
+typedef struct {
+    const float* ln_stats;
+    const float* ln_colsum;
+    const float* bias_f32;
+    float* stats_out;
+    int stats_ld;
+} seedmi_gemm_ext_t;
+int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
+                         const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group, int row_extra,
+                         const seedmi_gemm_ext_t* ext, void* workspace, size_t workspace_bytes, void* stream);
+/* (mean, rstd = rsqrt(var + eps)) of every row of x [rows, cols] bf16, fp32 statistics like nn.LayerNorm: directly from x ... */
+int seedmi_layernorm_stats_bf16(const void* x, int ldx, int rows, int cols, float eps, void* stats_f32x2, void* stream);
+/* ... or from the per-span (sum, sum of squares) partials [spans][stats_ld >= rows][2] a BIAS_RESIDUAL GEMM wrote (summed in span
+ * order: deterministic). */
+int seedmi_layernorm_stats_finalize(const void* partial_f32x2, int spans, int stats_ld, int rows, int cols, float eps,
+                                    void* stats_f32x2, void* stream);
 int seedmi_gemm_bf16_ws(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
                         const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group, int row_extra,
                         void* workspace, size_t workspace_bytes, void* stream);
@@ -167,6 +192,10 @@ typedef struct {
     const void *ln2_w, *ln2_b;      /* norm2                                            */
     const void *fc1_w, *fc1_b;      /* mlp.fc1 [F,D]                                    */
     const void *fc2_w, *fc2_b;      /* mlp.fc2 [D,F]                                    */
+    /* optional LayerNorm fold (all six or none): half(qkv.weight * norm1.weight), its fp32 row sums, fp32 qkv bias + qkv.weight norm1.bias;
+     * the same for fc1 with norm2.  NULL -> explicit LayerNorm launches. */
+    const void *qkv_wg, *qkv_cs, *qkv_bf;
+    const void *fc1_wg, *fc1_cs, *fc1_bf;
 } seedmi_vit_layer_t;
 
 typedef struct {

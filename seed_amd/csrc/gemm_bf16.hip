@@ -23,6 +23,7 @@
 #include <type_traits>
 #include "common.h"
 #include "seedmi_internal.h"
+#include "../../include/seedmi.h"
 
 // s_setprio(1) around the MFMA runs of the 256x256 kernel: measured neutral-to-negative (-0.5 % end to end), off by default
 #ifndef SEEDMI_GEMM_PRIO
@@ -70,6 +71,16 @@ struct GemmParams {
     float* sk_slabs;
     unsigned* sk_flags;
     unsigned sk_epoch;
+    // LayerNorm folded into the GEMM (eva_vit.py:199-202: norm1 -> qkv, norm2 -> fc1).  Consumer side (BIAS / BIAS_GELU): A holds the
+    // UN-normalised rows x, W holds half(weight * gamma); with (mean, rstd) of every row in ln_stats, s_n = sum_k W'[n][k] in ln_colsum
+    // and b'_n = bias_n + sum_k beta_k weight[n][k] in bias_f32 the epilogue forms  rstd * (acc - mean * s_n) + b'_n  =  LN(x) W^T + bias
+    // with ONE rounding (the reference rounds LN(x) to half first).  Producer side (BIAS_RESIDUAL): stats_out receives, per row and
+    // 64-column span, (sum, sum of squares) of the half outputs; seedmi_layernorm_stats_finalize turns them into (mean, rstd).
+    const float* ln_stats;
+    const float* ln_colsum;
+    const float* bias_f32;
+    float* stats_out;
+    int stats_ld;               // spans per row
     int prefetch_residual;      // BIAS_RESIDUAL on the 256x256 kernel: touch the residual tile during the K loop ("gemm_prefetch_residual")
     int residual_nt;            // BIAS_RESIDUAL output stores: 1 = streaming (non-temporal), 0 = ordinary ("gemm_residual_nt")
     int row_group, row_extra;   // patch-embed: out_row = m + (m / row_group) * row_extra + row_extra ; res_row = m % row_group + row_extra
@@ -118,20 +129,83 @@ SEEDMI_DEVINL bool gelu_in_table(uint32_t h) { return ((h & 0x7fffu) - (GELU_E_M
 // instead of half sectors: -7 % on the ViT QKV GEMM).
 struct NoHook { SEEDMI_DEVINL void operator()() const {} };
 
+// producer side of the LayerNorm fold: (sum, sum of squares) of one row's 16 packed half outputs of this lane, reduced over the four
+// lanes (li + 16 g) that share the row's 64-column span; every lane of the span returns the span's totals
+SEEDMI_DEVINL float2 row_stats(const uint32_t (&pk)[8], int nvalid) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float a = (2 * i < nvalid) ? lo_bf(pk[i]) : 0.f, b = (2 * i + 1 < nvalid) ? hi_bf(pk[i]) : 0.f;
+        s1 += a + b;
+        s2 = fmaf(a, a, fmaf(b, b, s2));
+    }
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    return make_float2(s1, s2);
+}
+// span-major partials, [span][stats_ld rows]: the 16 lanes li of a store write 128 contiguous bytes, and the finalize kernel (one thread per
+// row) reads every span plane coalesced.  Written by the span's first column group only.
+SEEDMI_DEVINL void store_row_stats(const GemmParams& p, float2 st, int m, int nb) {
+    if ((nb & 63) == 0 && m < p.M) *(float2*)(p.stats_out + ((size_t)(nb >> 6) * p.stats_ld + m) * 2) = st;
+}
+
+// LayerNorm fold, consumer side of the 256x256 kernel: where this lane finds the tile's fold operands in LDS (put there by the
+// tile's prologue LDS-DMA): cs = column sums of the lane's 16 columns (the folded bias 1 KiB behind them), st = (mean, rstd) of row li of
+// the wave's 128 rows (row 16 mi + li: + 128 mi bytes)
+struct FoldLds { const char* cs = nullptr; const char* st = nullptr; };
+// acc <- rstd * acc + (bias - mean * rstd * colsum), in place (the consumer epilogue then treats the accumulators as finished sums)
+SEEDMI_DEVINL void fold_accumulators(f32x4 (&acc)[8][4], const FoldLds& fold) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const f32x4 c4 = *(const f32x4*)(fold.cs + 16 * ni), b4 = *(const f32x4*)(fold.cs + 1024 + 16 * ni);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const float2 st = *(const float2*)(fold.st + 128 * mi);
+            const float nmr = -st.x * st.y;                                // -mean * rstd
+            const f32x4 t = __builtin_elementwise_fma((f32x4){nmr, nmr, nmr, nmr}, c4, b4);
+            acc[mi][ni] = __builtin_elementwise_fma((f32x4){st.y, st.y, st.y, st.y}, acc[mi][ni], t);
+        }
+    }
+}
+
 // after_loads: called once, after the epilogue's up-front loads have been issued AND waited for and before its first store (the
 // persistent kernel starts the next tile's LDS-DMA there: hipcc waits vmcnt(0) for every ordinary load while LDS-DMA is in flight,
 // so DMA issued ahead of the bias / residual loads puts its own latency into the epilogue's critical path)
-template <int EPI, int MT, bool LANE4 = true, typename Hook = NoHook>
+template <int EPI, int MT, bool LANE4 = true, typename Hook = NoHook, bool LNF = false>
 SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int mrow0, int nb, int li, const char* lut = nullptr,
                                  Hook after_loads = Hook()) {
     const int span0 = nb & ~63;                                   // first column of the wave's 64-column span (wave-uniform)
-    const bool span_full = LANE4 && EPI != EPI_SWIGLU && (span0 + 64 <= p.N) && p.skip_epilogue == 0;
-    if (nb >= p.N) { after_loads(); return; }
-    const bool full = (nb + 16 <= p.N);
+    // (the LayerNorm-fold variants require N % 64 == 0: a wave's span is inside N or outside it as a whole, no ragged code)
+    const bool span_full = LANE4 && EPI != EPI_SWIGLU && (LNF || span0 + 64 <= p.N) && p.skip_epilogue == 0;
+    if (nb >= p.N) {
+        after_loads();
+        return;
+    }
+    const bool full = LNF || (nb + 16 <= p.N);
+    const uint32_t wcol = (uint32_t)(span0 + 8 * ((nb >> 4) & 3));    // first column of the lane's pieces after the lane transposition
     float bias[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) bias[i] = 0.f;
-    if (EPI != EPI_NONE && p.bias) {
+    // LayerNorm fold, consumer side (BIAS / BIAS_GELU).  256x256 kernel (MT = 8): the tile's column sums, folded bias and (mean, rstd)
+    // pairs were brought into LDS by the tile's own prologue LDS-DMA (FoldLds): the epilogue has no global load at all and holds 10
+    // transient registers for them (held in registers - 32 column values + 16 row values next to 128 accumulators - the GELU variant
+    // spilled 130-210 B per lane, with reloads behind the tile's stores).  128x128 kernel (MT = 4): registers, loaded here.
+    constexpr bool CONSUME = LNF && EPI != EPI_BIAS_RESIDUAL;
+    constexpr bool FOLD_REGS = CONSUME && MT <= 4;
+    float csum[FOLD_REGS ? 16 : 1];
+    float2 rstat[FOLD_REGS ? MT : 1];
+    if (FOLD_REGS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // (unsigned 32-bit offsets from the kernel-argument bases: one offset register, not eight hoisted pointers)
+            const float4 c4 = *(const float4*)((const char*)p.ln_colsum + ((uint32_t)nb * 4u + 16u * i));
+            const float4 b4 = *(const float4*)((const char*)p.bias_f32 + ((uint32_t)nb * 4u + 16u * i));
+            csum[4 * i] = c4.x; csum[4 * i + 1] = c4.y; csum[4 * i + 2] = c4.z; csum[4 * i + 3] = c4.w;
+            bias[4 * i] = b4.x; bias[4 * i + 1] = b4.y; bias[4 * i + 2] = b4.z; bias[4 * i + 3] = b4.w;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+            rstat[mi] = *(const float2*)((const char*)p.ln_stats + 8u * (uint32_t)min(mrow0 + 16 * mi + li, p.M - 1));
+    } else if (!CONSUME && EPI != EPI_NONE && p.bias) {
         if (full) {
             const uint4 b0 = *(const uint4*)(p.bias + nb);
             const uint4 b1 = *(const uint4*)(p.bias + nb + 8);
@@ -145,6 +219,23 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
     if (!(EPI == EPI_BIAS_RESIDUAL || EPI == EPI_PATCH_EMBED)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bias[i]));     // the bias has landed
+        if (CONSUME) {
+            // the fold is applied to the accumulators in place, in a pass of its own: nothing of it lives through the activation /
+            // packing code below
+            if (FOLD_REGS) {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const float2 st = rstat[FOLD_REGS ? mi : 0];
+                    const float nmr = -st.x * st.y;                        // -mean * rstd
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[mi][ni][r] = fmaf(st.y, acc[mi][ni][r], fmaf(nmr, csum[4 * ni + r], bias[4 * ni + r]));
+                }
+            }                                                      // (MT = 8: the caller has already run fold_accumulators)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         after_loads();
     }
     // residual / pos_embed rows of ALL the lane's rows are requested up front: one exposed HBM latency per tile instead
@@ -173,10 +264,17 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
         const int m = mrow0 + 16 * mi + li;
         if (!span_full && m >= p.M) continue;                     // (the transposing path keeps every lane of the row alive)
         float v[16];
+        if (CONSUME) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[mi][ni][r] + bias[4 * ni + r];
+                for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[mi][ni][r];
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[mi][ni][r] + bias[4 * ni + r];
+        }
 
         int out_row = m;
         uint32_t pk[8];                                                    // packed result words (table path only)
@@ -231,6 +329,12 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             }
         }
 
+        if (EPI == EPI_BIAS_RESIDUAL && LNF) {
+            uint32_t spk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) spk[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+            store_row_stats(p, row_stats(spk, 16), m, nb);
+        }
         if (EPI == EPI_SWIGLU) {
             // interleaved rows: even = gate_proj, odd = up_proj  ->  out[m][n/2] = silu(gate) * up
             float o[8];
@@ -245,7 +349,8 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                 for (int i = 0; i < 8; ++i) if (nb + 2 * i + 1 < p.N) cp[i] = f2bf(o[i]);
             }
         } else {
-            bf16_t* cp = p.C + (size_t)out_row * p.ldc + nb;
+            // (element offsets fit 32 bits: the entry point refuses matrices of 2^31 elements or more)
+            bf16_t* cp = p.C + ((uint32_t)out_row * (uint32_t)p.ldc + (uint32_t)nb);
             if (full) {
                 uint4 s0, s1;
                 if (EPI == EPI_BIAS_GELU && packed) {
@@ -268,7 +373,7 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                         c[d] = t2[1];
                     }
                     if (m < p.M) {
-                        bf16_t* wp = p.C + (size_t)out_row * p.ldc + span0 + 8 * ((nb >> 4) & 3);
+                        bf16_t* wp = p.C + ((uint32_t)out_row * (uint32_t)p.ldc + wcol);
                         __builtin_nontemporal_store((u32x4_t){a[0], a[1], a[2], a[3]}, (u32x4_t*)wp);
                         __builtin_nontemporal_store((u32x4_t){c[0], c[1], c[2], c[3]}, (u32x4_t*)(wp + 32));
                     }
@@ -289,6 +394,9 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                     if (nb + i < p.N) cp[i] = (EPI == EPI_BIAS_GELU && packed) ? (bf16_t)((pk[i >> 1] >> (16 * (i & 1))) & 0xffffu) : f2bf(v[i]);
             }
         }
+        // (the fold variants have no ragged branches: without this the scheduler overlaps the rows' table reads across iterations
+        // until the straight-line code needs more than 256 registers)
+        if (CONSUME) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -300,10 +408,11 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
 // B = 256 over the bias-only epilogue.  Here the residual rows are fetched in two halves of 32 registers and the first half's
 // finished rows are HELD (packed, 32 registers, while their accumulators die) until the second half's loads have been issued: every
 // load of the epilogue precedes every store, nothing spills.
-template <typename Hook>
-SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li, Hook after_loads) {
+template <bool STATS, typename Hook>
+SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li, Hook after_loads,
+                                           char* stat_lds) {
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    const int span0 = nb & ~63;
+    const uint32_t wcol = (uint32_t)((nb & ~63) + 8 * ((nb >> 4) & 3));
     float bias[16];
     {
         const uint4 b0 = p.bias ? *(const uint4*)(p.bias + nb) : make_uint4(0, 0, 0, 0);
@@ -337,6 +446,11 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
         }
         unsigned a[4] = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
         unsigned c[4] = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+        if (STATS) {                                               // LayerNorm fold, producer side (before the lane transposition)
+            const uint32_t spk[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            const float2 st = row_stats(spk, 16);                  // parked in the wave's LDS slice: no register held, no store yet
+            if ((nb & 48) == 0) *(float2*)(stat_lds + 8 * (16 * mi_abs + li)) = st;
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const auto t1 = __builtin_amdgcn_permlane16_swap(a[d], c[d], false, false);
@@ -350,7 +464,7 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
     auto store_row = [&](int mi_abs, const u32x4_t& oa, const u32x4_t& oc) {
         const int m = mrow0 + 16 * mi_abs + li;
         if (m < p.M) {
-            bf16_t* wp = p.C + (size_t)m * p.ldc + span0 + 8 * ((nb >> 4) & 3);
+            bf16_t* wp = p.C + ((uint32_t)m * (uint32_t)p.ldc + wcol);
             if (p.residual_nt) {
                 __builtin_nontemporal_store(oa, (u32x4_t*)wp);
                 __builtin_nontemporal_store(oc, (u32x4_t*)(wp + 32));
@@ -383,6 +497,19 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
         finish_row(4 + mi, mi, oa, oc);
         store_row(4 + mi, oa, oc);
     }
+    if (STATS) {
+        // the wave's 128 (sum, sum of squares) pairs of this span: 1 KiB contiguous in the span's plane, two 512-byte store instructions
+        // (lane id taken here, by volatile asm: derived from threadIdx up front it is one more value held across the whole tile, and
+        // what hipcc then spills is reloaded right here, behind the tile's stores)
+        int lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = mrow0 + 64 * j + lane;
+            const float2 st = *(const float2*)(stat_lds + 8 * (64 * j + lane));
+            if (m < p.M) *(float2*)(p.stats_out + ((size_t)(nb >> 6) * p.stats_ld + m) * 2) = st;
+        }
+    }
 }
 
 // XCD-contiguous, grouped (GROUP_M m-tiles x all n-tiles) workgroup -> tile map
@@ -401,7 +528,7 @@ SEEDMI_DEVINL void tile_of_block(const GemmParams& p, int& tm, int& tn) {
     tn = in_g / gm;
 }
 
-template <int EPI>
+template <int EPI, bool LNF = false>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -475,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    gemm_epilogue<EPI, 4>(p, acc, m0 + 64 * wm, n0 + 64 * wn + 16 * g, li, lut);
+    gemm_epilogue<EPI, 4, true, NoHook, LNF>(p, acc, m0 + 64 * wm, n0 + 64 * wn + 16 * g, li, lut);
 }
 
 
@@ -539,7 +666,7 @@ SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid
     return n_seg;
 }
 
-template <int EPI>
+template <int EPI, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr bool PRIO = SEEDMI_GEMM_PRIO;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -566,6 +693,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // activation table) and read back one entry per tile: the walk then costs two SGPRs of state instead of a dozen.
     int* const segs = (int*)(smem + 2 * KT_BYTES + GELU_LUT_BYTES);
     constexpr int SCRATCH_OFF = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES;
+    // LayerNorm fold: consumers keep two 4 KiB operand sets here (this tile's and the next one's: column sums [256] f32 | folded bias
+    // [256] f32 | (mean, rstd) [256]); the producer (BIAS_RESIDUAL) parks 8 waves x 128 (sum, sum of squares) pairs
+    constexpr int STAT_OFF = SCRATCH_OFF + SCRATCH_BYTES;
+    constexpr bool FOLD_IN = LNF && EPI != EPI_BIAS_RESIDUAL;
+    int fold_par = 0;                                               // operand set the NEXT prologue fills
     const int n_seg = build_segments(p, nk, segs, tid);
     if (n_seg == 0) return;                                            // uniform for the whole workgroup
     if (EPI == EPI_BIAS_GELU) load_gelu_lut(smem + 2 * KT_BYTES, tid, 512);   // activation table behind the operand ring
@@ -584,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     next_seg(s_tile, s_kb, s_ke);
 
     int m0 = 0, n0 = 0;
-    int offA[2][2], offW[2][2];
+    uint32_t offA[2][2], offW[2][2];                    // element offsets (< 2^31, checked at the entry point): 32-bit, zero-extended
     // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
     auto set_tile = [&](int t) {
         const int gsize = p.group_m * p.tiles_n;
@@ -600,8 +732,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int j = 0; j < 2; ++j) {
                 const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
                 const int cs = lane & 7;
-                offA[h][j] = min(m0 + row, p.M - 1) * p.lda + 8 * (cs ^ swzA(row));
-                offW[h][j] = min(n0 + row, p.N - 1) * p.ldw + 8 * (cs ^ swzW(row));
+                offA[h][j] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(row));
+                offW[h][j] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldw + 8u * (uint32_t)(cs ^ swzW(row));
             }
     };
     // ---- fragment read bases (byte offsets inside a K-tile buffer); tile index adds an immediate
@@ -618,7 +750,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.A + (size_t)(offA[h][j] + k0), base + h * HALF_BYTES + j * 1024);
+            for (int j = 0; j < 2; ++j) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
     };
     auto stageW = [&](int kt) {
         char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
@@ -626,11 +758,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.W + (size_t)(offW[h][j] + k0), base + h * HALF_BYTES + j * 1024);
+            for (int j = 0; j < 2; ++j) glds16(p.W + (offW[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
     };
 
     // prologue loads of a segment: its first K-tile (A and W) and, already in flight behind it, W of the second
     auto issue_prologue = [&](int kb, int ke) {
+        if (FOLD_IN) {
+            // the tile's fold operands travel with its first K-tile, as its OLDEST LDS-DMA request (one 1 KiB piece per wave, waves
+            // 4-7 repeat pieces 0-3): complete, and published by the K loop's barriers, long before the epilogue reads them
+            const int piece = wave & 3;
+            const char* src;
+            if (piece == 0) src = (const char*)p.ln_colsum + 4u * (uint32_t)min(n0 + 4 * lane, p.N - 4);
+            else if (piece == 1) src = (const char*)p.bias_f32 + 4u * (uint32_t)min(n0 + 4 * lane, p.N - 4);
+            else src = (const char*)p.ln_stats + 8u * (uint32_t)min(m0 + 128 * (piece - 2) + 2 * lane, (p.M - 1) & ~1);
+            glds16((const bf16_t*)src, smem + STAT_OFF + fold_par * 4096 + piece * 1024);
+            fold_par ^= 1;
+        }
         stageA(kb);
         stageW(kb);
         if (kb + 1 < ke) stageW(kb + 1);
@@ -641,6 +784,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh) k0/k1 x 4 tiles ; W(nh0), W(nh1): k0/k1 x 2 tiles
     for (;;) {
     const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
+    const int fold_cur = fold_par ^ 1;                  // ... and its fold operand set
     const int kb = s_kb, ke = s_ke;                     // (s_* move on to the next segment before the epilogue)
     if (kb > 0) {
         // ---- K tail of a shared tile (always this workgroup's last segment): continue the accumulation of the workgroup in
@@ -784,6 +928,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
     SEEDMI_SCHED_FENCE();
 
+    if (FOLD_IN && ke == nk) {
+        // LayerNorm fold, applied while nothing but the accumulators is live (ahead of the next tile's address set-up: placed inside
+        // the epilogue it cost 110-290 B of scratch per lane, reloaded behind the tile's stores)
+        FoldLds fold;
+        fold.cs = smem + STAT_OFF + fold_cur * 4096 + 4 * (64 * wn + 16 * g);
+        fold.st = smem + STAT_OFF + fold_cur * 4096 + 2048 + 8 * (128 * wm + li);
+        fold_accumulators(acc, fold);
+        SEEDMI_SCHED_FENCE();
+    }
     // every LDS read of this segment is done: start the next segment's prologue loads now so that their latency (and the
     // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
     const bool more = next_seg(s_tile, s_kb, s_ke);
@@ -815,9 +968,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     } else {
         const int enb = en0 + 64 * wn + 16 * g;
         if (EPI == EPI_BIAS_RESIDUAL && p.skip_epilogue == 0 && (enb & ~63) + 64 <= p.N) {
-            gemm_epilogue_residual8(p, acc, em0 + 128 * wm, enb, li, hook);
+            gemm_epilogue_residual8<LNF>(p, acc, em0 + 128 * wm, enb, li, hook, smem + STAT_OFF + wave * 1024);
         } else if (p.skip_epilogue != 1) {
-            gemm_epilogue<EPI, 8, true>(p, acc, em0 + 128 * wm, enb, li, lut, hook);
+            gemm_epilogue<EPI, 8, true, decltype(hook), LNF>(p, acc, em0 + 128 * wm, enb, li, lut, hook);
         } else {
             hook();
             if (acc[0][0][0] == 123.456f) p.C[0] = 0;       // keep the accumulators alive
@@ -841,13 +994,13 @@ constexpr size_t SK_SLAB_BYTES = (size_t)B2 * B2 * 4;       // one fp32 accumula
 constexpr size_t SK_FLAGS_BYTES = 4096;                      // one flag word per workgroup (<= 1024 CUs)
 std::atomic<unsigned> g_sk_epoch{0};
 
-template <int EPI>
+template <int EPI, bool LNF = false>
 int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_bytes) {
-    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES;
+    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES + (LNF ? 8 * 1024 : 0);
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set[dev] = true;
     }
     p.tiles_m = (p.M + B2 - 1) / B2;
@@ -866,7 +1019,7 @@ int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_b
         if (e == 0) e = ++g_sk_epoch;                      // 0 is what a cleared flag area holds
         p.sk_epoch = e;
     }
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, LNF>), dim3(grid), dim3(512), lds, stream, p);
     return seedmi_check_launch("gemm256");
 }
 
@@ -874,21 +1027,21 @@ int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_b
 #include "gemm_devtools_k.inc"
 #endif
 
-template <int EPI>
+template <int EPI, bool LNF = false>
 int launch_gemm128(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = 2 * STAGE_BYTES + (EPI == EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set[dev] = true;
     }
     const int grid = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(gemm128_kernel<EPI>, dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((gemm128_kernel<EPI, LNF>), dim3(grid), dim3(256), lds, stream, p);
     return seedmi_check_launch("gemm128");
 }
 
-template <int EPI>
+template <int EPI, bool LNF = false>
 int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_bytes) {
     // the 256x256 kernel wants at least g_gemm_min_tiles tiles (one per CU is 256): below that the 128x128 kernel's four times
     // finer tiling fills the chip better (Q-Former GEMMs at M = B*32)
@@ -896,12 +1049,13 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
     const bool big = p.M >= 1024 && p.N >= 256 && tiles256 >= g_gemm_min_tiles;
     const int variant = g_gemm_variant;
 #ifdef SEEDMI_DEVTOOLS
+    if (LNF) return (variant == 128) ? launch_gemm128<EPI, LNF>(p, s) : launch_gemm256<EPI, LNF>(p, s, sk_ws, sk_ws_bytes);
     if (variant == 257 && EPI != EPI_SWIGLU && EPI != EPI_PATCH_EMBED) return launch_gemm256k<EPI>(p, s, sk_ws, sk_ws_bytes);
     if (variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
     if (variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
 #endif
     const bool use256 = variant == 256 || (variant == 0 && big);
-    return use256 ? launch_gemm256<EPI>(p, s, sk_ws, sk_ws_bytes) : launch_gemm128<EPI>(p, s);
+    return use256 ? launch_gemm256<EPI, LNF>(p, s, sk_ws, sk_ws_bytes) : launch_gemm128<EPI, LNF>(p, s);
 }
 
 }  // namespace
@@ -948,6 +1102,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
     }
     if (key && !strcmp(key, "tokenize_streams") && seedmi_tokenizer_set_streams(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_streamk") && seedmi_tokenizer_set_streamk(value) == SEEDMI_OK) return SEEDMI_OK;
+    if (key && !strcmp(key, "tokenize_lnfold") && seedmi_tokenizer_set_lnfold(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_llama_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_attn_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);
@@ -962,6 +1117,23 @@ extern "C" size_t seedmi_gemm_workspace_bytes(void) {
 extern "C" int seedmi_gemm_bf16_ws(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
                                    const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group,
                                    int row_extra, void* workspace, size_t workspace_bytes, void* stream) {
+    return seedmi_gemm_bf16_ext(M, N, K, A, lda, W, ldw, bias, residual, ldr, epilogue, C, ldc, row_group, row_extra, nullptr, workspace,
+                                workspace_bytes, stream);
+}
+
+extern "C" int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
+                                    const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group, int row_extra,
+                                    const seedmi_gemm_ext_t* ext, void* workspace, size_t workspace_bytes, void* stream) {
+    const bool lnf = ext && ext->ln_stats;
+    if (lnf && (!ext->ln_colsum || !ext->bias_f32 || (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU) || (N % 64) ||
+                (((uintptr_t)ext->ln_colsum | (uintptr_t)ext->bias_f32) & 15) || ((uintptr_t)ext->ln_stats & 7))) {
+        seedmi_set_error("seedmi_gemm_bf16_ext: the LayerNorm fold needs ln_stats, ln_colsum, bias_f32 (16-byte aligned), N %% 64 == 0 and the BIAS or BIAS_GELU epilogue");
+        return SEEDMI_E_SHAPE;
+    }
+    if (ext && ext->stats_out && (epilogue != EPI_BIAS_RESIDUAL || (N % 64) || ext->stats_ld < M)) {
+        seedmi_set_error("seedmi_gemm_bf16_ext: stats_out belongs to the BIAS_RESIDUAL epilogue and needs N %% 64 == 0 and stats_ld >= M");
+        return SEEDMI_E_SHAPE;
+    }
     if (workspace && (((uintptr_t)workspace & 255) || workspace_bytes < SK_FLAGS_BYTES)) {
         seedmi_set_error("seedmi_gemm_bf16_ws: workspace must be 256-byte aligned and hold seedmi_gemm_workspace_bytes()");
         return SEEDMI_E_ALIGN;
@@ -990,7 +1162,7 @@ extern "C" int seedmi_gemm_bf16_ws(int M, int N, int K, const void* A, int lda, 
         seedmi_set_error("seedmi_gemm_bf16: SWIGLU needs an even N (interleaved gate/up rows)");
         return SEEDMI_E_SHAPE;
     }
-    GemmParams p;
+    GemmParams p = {};
     p.M = M; p.N = N; p.K = K;
     p.A = (const bf16_t*)A; p.lda = lda;
     p.W = (const bf16_t*)W; p.ldw = ldw;
@@ -1005,14 +1177,24 @@ extern "C" int seedmi_gemm_bf16_ws(int M, int N, int K, const void* A, int lda, 
     p.skip_epilogue = (abl == 32) ? 1 : (abl == 33 ? 2 : (abl == 34 ? 3 : (abl == 35 ? 4 : 0)));
 #endif
     p.sk_slabs = nullptr; p.sk_flags = nullptr; p.sk_epoch = 0;
+    p.ln_stats = lnf ? ext->ln_stats : nullptr;
+    p.ln_colsum = lnf ? ext->ln_colsum : nullptr;
+    p.bias_f32 = lnf ? ext->bias_f32 : nullptr;
+    p.stats_out = ext ? ext->stats_out : nullptr;
+    p.stats_ld = ext ? ext->stats_ld : 0;
+    p.prefetch_residual = g_gemm_prefetch_r;
+    p.residual_nt = g_gemm_residual_nt;
     p.row_group = row_group > 0 ? row_group : 1;
     p.row_extra = row_extra;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case EPI_NONE: return launch_gemm<EPI_NONE>(p, s, workspace, workspace_bytes);
-        case EPI_BIAS: return launch_gemm<EPI_BIAS>(p, s, workspace, workspace_bytes);
-        case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(p, s, workspace, workspace_bytes);
-        case EPI_BIAS_RESIDUAL: return launch_gemm<EPI_BIAS_RESIDUAL>(p, s, workspace, workspace_bytes);
+        case EPI_BIAS: return lnf ? launch_gemm<EPI_BIAS, true>(p, s, workspace, workspace_bytes) : launch_gemm<EPI_BIAS>(p, s, workspace, workspace_bytes);
+        case EPI_BIAS_GELU:
+            return lnf ? launch_gemm<EPI_BIAS_GELU, true>(p, s, workspace, workspace_bytes) : launch_gemm<EPI_BIAS_GELU>(p, s, workspace, workspace_bytes);
+        case EPI_BIAS_RESIDUAL:
+            return p.stats_out ? launch_gemm<EPI_BIAS_RESIDUAL, true>(p, s, workspace, workspace_bytes)
+                               : launch_gemm<EPI_BIAS_RESIDUAL>(p, s, workspace, workspace_bytes);
         case EPI_BIAS_TANH: return launch_gemm<EPI_BIAS_TANH>(p, s, workspace, workspace_bytes);
         case EPI_SWIGLU: return launch_gemm<EPI_SWIGLU>(p, s, workspace, workspace_bytes);
         case EPI_PATCH_EMBED: return launch_gemm<EPI_PATCH_EMBED>(p, s, workspace, workspace_bytes);

@@ -95,6 +95,61 @@ __global__ __launch_bounds__(64 * NORM_WAVES) void norm_kernel(const bf16_t* __r
     }
 }
 
+// LayerNorm statistics only (the normalisation itself is folded into the consuming GEMM, seedmi_gemm_bf16_ext): one wave per row,
+// two-pass variance like norm_kernel
+template <int MAXC>
+__global__ __launch_bounds__(64 * NORM_WAVES) void row_stats_kernel(const bf16_t* __restrict__ x, int ldx, float eps,
+                                                                    float2* __restrict__ out, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * NORM_WAVES + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunks = cols >> 3;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float v[MAXC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (c < nchunks) u = *(const uint4*)(xr + 8 * c);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[i][2 * j] = lo_bf(w[j]);
+            v[i][2 * j + 1] = hi_bf(w[j]);
+            sum += v[i][2 * j] + v[i][2 * j + 1];
+        }
+    }
+    sum = wave_sum(sum);
+    const float inv_n = 1.0f / (float)cols;
+    const float mean = sum * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+        }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) out[row] = make_float2(mean, rsqrtf(sq * inv_n + eps));
+}
+
+// (sum, sum of squares) partials per 64-column span, span-major planes of ld rows -> (mean, rstd); one thread per row (every plane is
+// read coalesced), spans summed in index order
+__global__ void stats_finalize_kernel(const float2* __restrict__ part, int spans, int ld, int rows, float inv_n, float eps,
+                                      float2* __restrict__ out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float2* pr = part + row;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < spans; ++i) { const float2 t = pr[(size_t)i * ld]; s1 += t.x; s2 += t.y; }
+    const float mean = s1 * inv_n;
+    const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+    out[row] = make_float2(mean, rsqrtf(var + eps));
+}
+
 template <bool RMS, bool PACK = false>
 int launch_norm(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* out, int ldo, int rows,
                 int cols, hipStream_t s) {
@@ -257,6 +312,41 @@ extern "C" int seedmi_layernorm_bf16(const void* x, int ldx, const void* gamma, 
         return SEEDMI_E_SHAPE;
     }
     return launch_norm<false>(x, ldx, gamma, beta, eps, out, ldo, rows, cols, (hipStream_t)stream);
+}
+
+extern "C" int seedmi_layernorm_stats_bf16(const void* x, int ldx, int rows, int cols, float eps, void* stats, void* stream) {
+    if (!x || !stats || rows <= 0 || cols <= 0 || (cols % 8) || (ldx % 8) || cols > 8192) {
+        seedmi_set_error("seedmi_layernorm_stats_bf16: rows=%d cols=%d ldx=%d", rows, cols, ldx);
+        return SEEDMI_E_SHAPE;
+    }
+    const int grid = (rows + NORM_WAVES - 1) / NORM_WAVES;
+    const int chunks = cols / 8;
+    hipStream_t s = (hipStream_t)stream;
+#define SEEDMI_STATS_CASE(MAXC_)                                                                                          \
+    if (chunks <= 64 * MAXC_) {                                                                                           \
+        hipLaunchKernelGGL((row_stats_kernel<MAXC_>), dim3(grid), dim3(64 * NORM_WAVES), 0, s, (const bf16_t*)x, ldx, eps,  \
+                           (float2*)stats, rows, cols);                                                                   \
+        return seedmi_check_launch("row_stats");                                                                          \
+    }
+    SEEDMI_STATS_CASE(1)
+    SEEDMI_STATS_CASE(2)
+    SEEDMI_STATS_CASE(3)
+    SEEDMI_STATS_CASE(4)
+    SEEDMI_STATS_CASE(8)
+    SEEDMI_STATS_CASE(16)
+#undef SEEDMI_STATS_CASE
+    return SEEDMI_E_SHAPE;
+}
+
+extern "C" int seedmi_layernorm_stats_finalize(const void* partial, int spans, int stats_ld, int rows, int cols, float eps, void* stats,
+                                               void* stream) {
+    if (!partial || !stats || spans <= 0 || stats_ld < rows || rows <= 0 || cols <= 0) {
+        seedmi_set_error("seedmi_layernorm_stats_finalize: bad arguments");
+        return SEEDMI_E_SHAPE;
+    }
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float2*)partial, spans,
+                       stats_ld, rows, 1.0f / (float)cols, eps, (float2*)stats);
+    return seedmi_check_launch("stats_finalize");
 }
 
 extern "C" int seedmi_rmsnorm_bf16(const void* x, int ldx, const void* gamma, float eps, void* out, int ldo, int rows,

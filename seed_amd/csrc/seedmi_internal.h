@@ -17,6 +17,7 @@ enum {
 // seedmi_set_option("tokenize_streams", 1|2): sub-batch overlap inside seedmi_tokenize (tokenizer.hip)
 int seedmi_tokenizer_set_streams(int n);
 int seedmi_tokenizer_set_streamk(int v);
+int seedmi_tokenizer_set_lnfold(int v);
 // seedmi_set_option("skinny_nt" | "skinny_waves", v): decode GEMM experiments (llama.hip)
 int seedmi_llama_set_option(const char* key, int value);
 int seedmi_attn_set_option(const char* key, int value);

@@ -29,12 +29,15 @@ struct Carver {
 
 struct TokWs {
     bf16_t *col, *x, *xn, *qkv, *h, *kv, *qx, *qa, *qt, *qqkv, *qh, *z;
+    float *stats, *spart;     // LayerNorm fold: (mean, rstd) per row; per-span (sum, sumsq) partials of the last residual GEMM
+    int spans;
     void* sk;                 // stream-K workspace of the big GEMMs (flags in its first 4 KiB, cleared at the start of every call)
     size_t sk_bytes;
     size_t bytes;
 };
 
 int g_tok_streamk = 0;                    // seedmi_set_option("tokenize_streamk", 0|1)
+int g_tok_lnfold = 1;                     // seedmi_set_option("tokenize_lnfold", 0|1): LayerNorm folded into qkv / fc1 when the weights carry it
 
 TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
     const int grid = w->img_size / w->patch;
@@ -55,6 +58,9 @@ TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
     t.qqkv = (bf16_t*)c.take(Mq * 3 * Q * 2);
     t.qh = (bf16_t*)c.take(Mq * FF * 2);
     t.z = (bf16_t*)c.take(Mq * 64 * 2);
+    t.spans = (int)((D + 63) / 64);
+    t.stats = (float*)c.take((M + 1) * 2 * sizeof(float));      // (the fold's LDS-DMA reads row pairs: one row of slack)
+    t.spart = (float*)c.take(M * t.spans * 2 * sizeof(float));
     t.sk_bytes = seedmi_gemm_workspace_bytes();
     t.sk = c.take(t.sk_bytes);
     t.bytes = c.off;
@@ -116,12 +122,33 @@ int run_phase(const Part& p, int phase) {
         CK(GEMM_WS(B * P, D, w->kpad, t.col, w->kpad, w->patch_w, w->kpad, w->patch_b, w->pos_embed, D,
                    SEEDMI_EPI_PATCH_EMBED, t.x, D, P, 1));
         CK(seedmi_fill_rows(t.x, D, NT, 0, B, w->cls_pos0, D, 1, D, s));
+        if (g_tok_lnfold && w->vit_depth > 0 && w->vit[0].qkv_wg)      // statistics of block 0's norm1 (later ones come from the GEMMs)
+            CK(seedmi_layernorm_stats_bf16(t.x, D, M, D, 1e-6f, t.stats, s));
         return SEEDMI_OK;
     }
     phase -= 1;
     if (phase < w->vit_depth) {                                             // Block.forward (eva_vit.py:199-202)
         const seedmi_vit_layer_t& L = w->vit[phase];
         const float vit_scale = 1.0f / sqrtf((float)hd);
+        if (g_tok_lnfold && L.qkv_wg) {
+            // LayerNorm folded into the GEMMs around it: qkv / fc1 read the residual stream itself (weights carry gamma, the epilogue
+            // applies mean / rstd / beta), proj / fc2 emit the row statistics of what they write.  78 LayerNorm passes over the token
+            // stream (read + write 0.37 GB each at B = 256) become 78 reductions of 22 partials per row.
+            seedmi_gemm_ext_t e_qkv = {t.stats, (const float*)L.qkv_cs, (const float*)L.qkv_bf, nullptr, 0};
+            seedmi_gemm_ext_t e_fc1 = {t.stats, (const float*)L.fc1_cs, (const float*)L.fc1_bf, nullptr, 0};
+            seedmi_gemm_ext_t e_res = {nullptr, nullptr, nullptr, t.spart, (int)M};
+            void* sk = g_tok_streamk ? t.sk : nullptr;
+            const size_t skb = g_tok_streamk ? t.sk_bytes : 0;
+            CK(seedmi_gemm_bf16_ext(M, 3 * D, D, t.x, D, L.qkv_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, 0, 0, &e_qkv, sk, skb, s));
+            CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
+                                     vit_scale, 0, 1, s));
+            CK(seedmi_gemm_bf16_ext(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, &e_res, sk, skb, s));
+            CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
+            CK(seedmi_gemm_bf16_ext(M, F, D, t.x, D, L.fc1_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, 0, 0, &e_fc1, sk, skb, s));
+            CK(seedmi_gemm_bf16_ext(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, &e_res, sk, skb, s));
+            if (phase + 1 < w->vit_depth) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
+            return SEEDMI_OK;
+        }
         CK(seedmi_layernorm_bf16(t.x, D, L.ln1_w, L.ln1_b, 1e-6f, t.xn, D, M, D, s));
         CK(GEMM_WS(M, 3 * D, D, t.xn, D, L.qkv_w, D, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, 0, 0));
         CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
@@ -224,6 +251,11 @@ size_t total_ws(const seedmi_tokenizer_weights_t* w, int batch) { return ws_for(
 int seedmi_tokenizer_set_streams(int n) {
     if (n < 1 || n > MAX_PARTS) return SEEDMI_E_SHAPE;
     g_tok_streams = n;
+    return SEEDMI_OK;
+}
+int seedmi_tokenizer_set_lnfold(int v) {
+    if (v != 0 && v != 1) return SEEDMI_E_SHAPE;
+    g_tok_lnfold = v;
     return SEEDMI_OK;
 }
 int seedmi_tokenizer_set_streamk(int v) {

@@ -18,7 +18,12 @@ _i = C.c_int
 
 class VitLayer(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b",
-                                    "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+                                    "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                    "qkv_wg", "qkv_cs", "qkv_bf", "fc1_wg", "fc1_cs", "fc1_bf")]     # LayerNorm fold (optional)
+
+
+class GemmExt(C.Structure):
+    _fields_ = [("ln_stats", _vp), ("ln_colsum", _vp), ("bias_f32", _vp), ("stats_out", _vp), ("stats_ld", _i)]
 
 
 class QfLayer(C.Structure):
@@ -68,6 +73,10 @@ SIGNATURES = {
     "seedmi_set_option": (_i, [C.c_char_p, _i]),
     "seedmi_gemm_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "seedmi_gemm_workspace_bytes": (C.c_size_t, []),
+    "seedmi_gemm_bf16_ext": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, C.POINTER(GemmExt), _vp, C.c_size_t,
+                                  _vp]),
+    "seedmi_layernorm_stats_bf16": (_i, [_vp, _i, _i, _i, C.c_float, _vp, _vp]),
+    "seedmi_layernorm_stats_finalize": (_i, [_vp, _i, _i, _i, _i, C.c_float, _vp, _vp]),
     "seedmi_gemm_bf16_ws": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, C.c_size_t, _vp]),
     "seedmi_layernorm_bf16": (_i, [_vp, _i, _vp, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
     "seedmi_rmsnorm_bf16": (_i, [_vp, _i, _vp, C.c_float, _vp, _i, _i, _i, _vp]),

