@@ -50,7 +50,8 @@ int seedmi_check_device(void);
  * workspace is passed), "gemm_group_m" (1..64 m-tiles per L2 tile group), "gemm_min_tiles" (256x256 kernel only at or above this
  * many tiles), "tokenize_streams" (1..4 concurrent sub-batches inside seedmi_tokenize), "tokenize_streamk" (0|1: stream-K
  * tail for the tokenizer's big GEMMs, default 0), "tokenize_lnfold" (0|1: LayerNorm folded into qkv / fc1 when the weights carry
- * the folded copies, default 1), "skinny_nt" / "skinny_waves" / "skinny_rows"
+ * the folded copies, default 1), "tokenize_split_rounds" (0|1: a big GEMM whose 256x256 tiles overshoot a whole number of rounds by
+ * a few m-tiles runs those rows as a second, 128x128-tiled call; pays on one stream only, default 0), "skinny_nt" / "skinny_waves" / "skinny_rows"
  * (decode GEMM), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
  * (attention kernel selection).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */

@@ -108,7 +108,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int U = (R * MT > 4) ? 2 : 4;                          // k-steps per register set (bounded by the VGPR budget)
+    // k-steps per register set (bounded by the VGPR budget).  Tried for the N = 4096 projections (R = 1, one workgroup per CU): U = 8,
+    // 128 KB of weight loads in flight per CU instead of 64 - 18.5 vs 18.9 us per launch (profiles/r02 run 13): depth is not what holds
+    // o_proj / down at 3.1-3.3 TB/s, so the smaller register set stays (two workgroups per CU where the grid has them).
+    constexpr int U = (R * MT > 4) ? 2 : 4;
     bf16x8 w0[U][R], a0[U][MT], w1[U][R], a1[U][MT];
     const int nb = (kslice + 32 * U - 1) / (32 * U);
     auto load = [&](bf16x8 (&wf)[U][R], bf16x8 (&af)[U][MT], int b) {

@@ -37,6 +37,7 @@ struct TokWs {
 };
 
 int g_tok_streamk = 0;                    // seedmi_set_option("tokenize_streamk", 0|1)
+int g_tok_split = 0;                      // seedmi_set_option("tokenize_split_rounds", 0|1): whole rounds of 256x256 tiles + a 128x128 remainder
 int g_tok_lnfold = 1;                     // seedmi_set_option("tokenize_lnfold", 0|1): LayerNorm folded into qkv / fc1 when the weights carry it
 
 TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
@@ -100,9 +101,50 @@ int n_phases(const seedmi_tokenizer_weights_t* w) { return 1 + w->vit_depth + 1 
 // measured at B = 256 (tools/tok_ab.py, profiles/r02_tok_ab.json) the two sub-batch streams already fill every kernel's partial last
 // round with the other stream's workgroups (134.9 ms per pass), and stream-K's balanced endings take that overlap away (141.5 ms);
 // on one stream it is neutral (140.6 vs 140.8 ms).  It pays for isolated GEMM calls (seedmi_gemm_bf16_ws: +2..4 %).
+// A big GEMM as whole rounds plus a remainder.  The persistent 256x256 kernel runs ceil(tiles / CUs) rounds; B = 256 images are
+// 256 + 1 m-tiles (257 tokens each), so the N = 1408 GEMMs (6 n-tiles) were 1542 tiles = 6.02 rounds: a seventh round on six CUs, 14 %
+// of proj / fc2.  When dropping the last few m-tiles saves a whole round, those rows go to a second call, which the library sends to the
+// 128x128 kernel (M < 1024): a quarter of a round on 2 x 11 workgroups.  Pointers of the row-indexed operands are offset; results are
+// those of the single call (each output element's K chain does not depend on the tile shape; tools/tok_ab.py checks the ids).
+// Measured at B = 256 (profiles/r02_tok_ab.json): one stream 131.0 vs 132.6 ms, two streams 129.0 vs 126.6 ms - with two sub-batch
+// streams the other stream's kernels already run in the empty part of a last round and the extra launches only cost.  Off by default
+// (the default is two streams); seedmi_set_option("tokenize_split_rounds", 1) for single-stream callers.
+int gemm_rounds(int M, int N, int K, const bf16_t* A, int lda, const void* W, int ldw, const void* bias, const bf16_t* R, int ldr, int epi,
+                bf16_t* C, int ldc, const seedmi_gemm_ext_t* ext, void* sk, size_t skb, void* s) {
+    int m_main = M;
+    if (g_tok_split && M >= 2048) {
+        const int cus = seedmi_device_cus(seedmi_current_device());
+        const int tn = (N + 255) / 256, tm = (M + 255) / 256;
+        const int rounds = (tm * tn + cus - 1) / cus;
+        for (int drop = 1; drop <= 3 && drop < tm; ++drop) {         // rows of the last `drop` m-tiles -> remainder
+            const int r2 = ((tm - drop) * tn + cus - 1) / cus;
+            if (r2 < rounds && M - (tm - drop) * 256 < 1024) { m_main = (tm - drop) * 256; break; }
+        }
+    }
+    CK(seedmi_gemm_bf16_ext(m_main, N, K, A, lda, W, ldw, bias, R, ldr, epi, C, ldc, 0, 0, ext, sk, skb, s));
+    if (m_main < M) {
+        seedmi_gemm_ext_t e2 = {nullptr, nullptr, nullptr, nullptr, 0};
+        if (ext) {
+            e2 = *ext;
+            if (e2.ln_stats) e2.ln_stats += 2 * (size_t)m_main;
+            if (e2.stats_out) e2.stats_out += 2 * (size_t)m_main;           // (span-major planes: the plane stride stays stats_ld)
+        }
+        CK(seedmi_gemm_bf16_ext(M - m_main, N, K, A + (size_t)m_main * lda, lda, W, ldw, bias, R ? R + (size_t)m_main * ldr : nullptr, ldr, epi,
+                                C + (size_t)m_main * ldc, ldc, 0, 0, ext ? &e2 : nullptr, nullptr, 0, s));
+    }
+    return SEEDMI_OK;
+}
+
+// big GEMMs (M = B * 257 rows): with seedmi_set_option("tokenize_streamk", 1) they take the stream-K workspace.  Off by default:
+// measured at B = 256 (tools/tok_ab.py, profiles/r02_tok_ab.json) the two sub-batch streams already fill every kernel's partial last
+// round with the other stream's workgroups (134.9 ms per pass), and stream-K's balanced endings take that overlap away (141.5 ms);
+// on one stream it is neutral (140.6 vs 140.8 ms).  It pays for isolated GEMM calls (seedmi_gemm_bf16_ws: +2..4 %).
 #define GEMM_WS(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, rg_, re_) \
     seedmi_gemm_bf16_ws(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, rg_, re_, g_tok_streamk ? t.sk : nullptr, \
                         g_tok_streamk ? t.sk_bytes : 0, s)
+#define GEMM_R(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, ext_) \
+    gemm_rounds(M_, N_, K_, A_, lda_, W_, ldw_, b_, R_, ldr_, epi_, C_, ldc_, ext_, g_tok_streamk ? t.sk : nullptr, \
+                g_tok_streamk ? t.sk_bytes : 0, s)
 
 int run_phase(const Part& p, int phase) {
     const seedmi_tokenizer_weights_t* w = p.w;
@@ -137,26 +179,24 @@ int run_phase(const Part& p, int phase) {
             seedmi_gemm_ext_t e_qkv = {t.stats, (const float*)L.qkv_cs, (const float*)L.qkv_bf, nullptr, 0};
             seedmi_gemm_ext_t e_fc1 = {t.stats, (const float*)L.fc1_cs, (const float*)L.fc1_bf, nullptr, 0};
             seedmi_gemm_ext_t e_res = {nullptr, nullptr, nullptr, t.spart, (int)M};
-            void* sk = g_tok_streamk ? t.sk : nullptr;
-            const size_t skb = g_tok_streamk ? t.sk_bytes : 0;
-            CK(seedmi_gemm_bf16_ext(M, 3 * D, D, t.x, D, L.qkv_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, 0, 0, &e_qkv, sk, skb, s));
+            CK(GEMM_R(M, 3 * D, D, t.x, D, L.qkv_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, &e_qkv));
             CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
                                      vit_scale, 0, 1, s));
-            CK(seedmi_gemm_bf16_ext(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, &e_res, sk, skb, s));
+            CK(GEMM_R(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, &e_res));
             CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
-            CK(seedmi_gemm_bf16_ext(M, F, D, t.x, D, L.fc1_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, 0, 0, &e_fc1, sk, skb, s));
-            CK(seedmi_gemm_bf16_ext(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0, &e_res, sk, skb, s));
+            CK(GEMM_R(M, F, D, t.x, D, L.fc1_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, &e_fc1));
+            CK(GEMM_R(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, &e_res));
             if (phase + 1 < w->vit_depth) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
             return SEEDMI_OK;
         }
         CK(seedmi_layernorm_bf16(t.x, D, L.ln1_w, L.ln1_b, 1e-6f, t.xn, D, M, D, s));
-        CK(GEMM_WS(M, 3 * D, D, t.xn, D, L.qkv_w, D, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, 0, 0));
+        CK(GEMM_R(M, 3 * D, D, t.xn, D, L.qkv_w, D, L.qkv_b, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, nullptr));
         CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
                                  vit_scale, 0, 1, s));
-        CK(GEMM_WS(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0));
+        CK(GEMM_R(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, nullptr));
         CK(seedmi_layernorm_bf16(t.x, D, L.ln2_w, L.ln2_b, 1e-6f, t.xn, D, M, D, s));
-        CK(GEMM_WS(M, F, D, t.xn, D, L.fc1_w, D, L.fc1_b, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, 0, 0));
-        CK(GEMM_WS(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, 0, 0));
+        CK(GEMM_R(M, F, D, t.xn, D, L.fc1_w, D, L.fc1_b, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, nullptr));
+        CK(GEMM_R(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, nullptr));
         return SEEDMI_OK;
     }
     phase -= w->vit_depth;
@@ -256,6 +296,11 @@ int seedmi_tokenizer_set_streams(int n) {
 int seedmi_tokenizer_set_lnfold(int v) {
     if (v != 0 && v != 1) return SEEDMI_E_SHAPE;
     g_tok_lnfold = v;
+    return SEEDMI_OK;
+}
+int seedmi_tokenizer_set_split(int v) {
+    if (v != 0 && v != 1) return SEEDMI_E_SHAPE;
+    g_tok_split = v;
     return SEEDMI_OK;
 }
 int seedmi_tokenizer_set_streamk(int v) {
