@@ -822,108 +822,126 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
     SEEDMI_SCHED_FENCE();
 
-    for (int kt = kb; kt < ke; ++kt) {
-        const char* sb = smem + (kt & 1) * KT_BYTES;
-        const char* pa0 = sb + rdA0;                    // k-step 0
-        const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
-        const char* pw0 = sb + rdW0;
-        const char* pw1 = sb + (rdW0 ^ 64);
+    // A wave whose 64-column span lies beyond N (the half-empty last n-tile of N = 1408: the column groups wn = 2, 3) has nothing to
+    // compute.  It walks the same barriers and issues its share of the LDS-DMA, but reads no fragments and issues no MFMA: the tile's
+    // live waves keep the LDS bandwidth and the power budget to themselves (proj -2 %, fc2 -2.9 % at B = 256).
+    const bool live = (en0 + 64 * wn) < p.N;
+    if (live) {
+        for (int kt = kb; kt < ke; ++kt) {
+            const char* sb = smem + (kt & 1) * KT_BYTES;
+            const char* pa0 = sb + rdA0;                    // k-step 0
+            const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
+            const char* pw0 = sb + rdW0;
+            const char* pw1 = sb + (rdW0 ^ 64);
 
-        // ================= P1: (mh0, nh0) =================
+            // ================= P1: (mh0, nh0) =================
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(pw0 + t * 512); fw0[2 + t] = *(const bf16x8*)(pw1 + t * 512); }
+            for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(pw0 + t * 512); fw0[2 + t] = *(const bf16x8*)(pw1 + t * 512); }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
-        if (kt + 1 < ke) stageA(kt + 1);
-        if (EPI == EPI_BIAS_RESIDUAL && p.prefetch_residual) {
-            // The epilogue reads this tile's 128 KB of residual.  Left to the epilogue, all CUs ask HBM for their tiles in the same
-            // few microseconds (32 MB per round) while C goes the other way: measured +81 us on the proj GEMM, +68 us on fc2 (B = 256)
-            // over the bias-only epilogue.  Touch the wave's 128 x 128-byte residual block in four pieces spread over the last twelve
-            // K-tiles instead (one dword per 64-byte line by LDS-DMA into a scratch row: no VGPR destination, retired by this
-            // K-tile's own vmcnt(0) three phases later), so the lines wait in the Infinity Cache / L2 when the epilogue asks.
-            const int rem = ke - 1 - kt;
-            if (rem == 12 || rem == 9 || rem == 6 || rem == 3) {
-                const int j = (12 - rem) / 3;
-                const int col = n0 + 64 * wn + 32 * (j & 1);
-                if (col < p.N) {
-                    const int row = min(m0 + 128 * wm + 64 * (j >> 1) + lane, p.M - 1);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.R + (size_t)row * p.ldr + col),
-                                                     (__attribute__((address_space(3))) void*)(smem + SCRATCH_OFF + wave * 256), 4, 0, 0);
+            for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
+            if (kt + 1 < ke) stageA(kt + 1);
+            if (EPI == EPI_BIAS_RESIDUAL && p.prefetch_residual) {
+                // The epilogue reads this tile's 128 KB of residual.  Left to the epilogue, all CUs ask HBM for their tiles in the same
+                // few microseconds (32 MB per round) while C goes the other way: measured +81 us on the proj GEMM, +68 us on fc2 (B = 256)
+                // over the bias-only epilogue.  Touch the wave's 128 x 128-byte residual block in four pieces spread over the last twelve
+                // K-tiles instead (one dword per 64-byte line by LDS-DMA into a scratch row: no VGPR destination, retired by this
+                // K-tile's own vmcnt(0) three phases later), so the lines wait in the Infinity Cache / L2 when the epilogue asks.
+                const int rem = ke - 1 - kt;
+                if (rem == 12 || rem == 9 || rem == 6 || rem == 3) {
+                    const int j = (12 - rem) / 3;
+                    const int col = n0 + 64 * wn + 32 * (j & 1);
+                    if (col < p.N) {
+                        const int row = min(m0 + 128 * wm + 64 * (j >> 1) + lane, p.M - 1);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.R + (size_t)row * p.ldr + col),
+                                                         (__attribute__((address_space(3))) void*)(smem + SCRATCH_OFF + wave * 256), 4, 0, 0);
+                    }
                 }
             }
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SEEDMI_SCHED_FENCE();
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+
+            // ================= P2: (mh0, nh1) =================
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { fw1[t] = *(const bf16x8*)(pw0 + (2 + t) * 512); fw1[2 + t] = *(const bf16x8*)(pw1 + (2 + t) * 512); }
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SEEDMI_SCHED_FENCE();
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+
+            // ================= P3: (mh1, nh1) =================
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SEEDMI_SCHED_FENCE();
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+
+            // ================= P4: (mh1, nh0) =================
+            // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kt + 2 < ke) stageW(kt + 2);               // W slots of this parity were last read in P2
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+            SEEDMI_SCHED_FENCE();
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
         }
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SEEDMI_SCHED_FENCE();
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+    } else {
+        for (int kt = kb; kt < ke; ++kt) {
+            if (kt + 1 < ke) stageA(kt + 1);
+            SEEDMI_SCHED_FENCE();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-
-        // ================= P2: (mh0, nh1) =================
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { fw1[t] = *(const bf16x8*)(pw0 + (2 + t) * 512); fw1[2 + t] = *(const bf16x8*)(pw1 + (2 + t) * 512); }
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SEEDMI_SCHED_FENCE();
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-
-        // ================= P3: (mh1, nh1) =================
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SEEDMI_SCHED_FENCE();
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-
-        // ================= P4: (mh1, nh0) =================
-        // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (kt + 2 < ke) stageW(kt + 2);               // W slots of this parity were last read in P2
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
-        SEEDMI_SCHED_FENCE();
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        SEEDMI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();
+            for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_barrier();      // P1, P2, P3: two barriers each
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kt + 2 < ke) stageW(kt + 2);
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();                                  // P4
+            __builtin_amdgcn_s_barrier();
+        }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
     SEEDMI_SCHED_FENCE();
