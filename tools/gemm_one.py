@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""Run one GEMM shape/kernel a few times (for rocprofv3 --pmc passes):  gemm_one.py <variant> <M> <N> <K> [iters]"""
+"""Run one GEMM shape/kernel a few times (for rocprofv3 --pmc passes):  gemm_one.py <variant> <M> <N> <K> [iters]
+FOLD=1 (default): the launch seedmi_tokenize issues for the ViT QKV GEMM - LayerNorm folded in (seedmi_gemm_bf16_ext, BIAS epilogue,
+kernel gemm256_kernel<1, true>); FOLD=0: the plain nn.Linear form (seedmi_gemm_bf16, gemm256_kernel<1, false>)."""
+import ctypes
 import os
 import sys
 
@@ -17,7 +20,17 @@ W = (torch.randn(N, K, device="cuda", generator=g) * 0.02).bfloat16()
 bias = torch.zeros(N, device="cuda").bfloat16()
 C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 L.check(lib.seedmi_set_option(b"gemm", v), "opt")
+fold = os.environ.get("FOLD", "1") == "1" and N % 64 == 0
+if fold:
+    stats = torch.zeros(M + (M & 1), 2, dtype=torch.float32, device="cuda")
+    L.check(lib.seedmi_layernorm_stats_bf16(L.ptr(A), K, M, K, 1e-6, L.ptr(stats), L.stream_ptr()), "stats")
+    cs, b32 = W.float().sum(1).contiguous(), bias.float().contiguous()
+    ext = L.GemmExt(L.ptr(stats), L.ptr(cs), L.ptr(b32), None, 0)
 for _ in range(iters):
-    L.check(lib.seedmi_gemm_bf16(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(C), N, 0, 0,
-                                 L.stream_ptr()), "gemm")
+    if fold:
+        L.check(lib.seedmi_gemm_bf16_ext(M, N, K, L.ptr(A), K, L.ptr(W), K, None, None, 0, L.EPI_BIAS, L.ptr(C), N, 0, 0, ctypes.byref(ext),
+                                         None, 0, L.stream_ptr()), "gemm ext")
+    else:
+        L.check(lib.seedmi_gemm_bf16(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(C), N, 0, 0,
+                                     L.stream_ptr()), "gemm")
 torch.cuda.synchronize()

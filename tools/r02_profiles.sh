@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02p/bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/r02p/bench.log 2>&1)
 find gpurun_out/r02p/bench -name '*kernel_stats.csv' -exec cp {} gpurun_out/r02p/bench_kernel_stats.csv \;
 rm -rf gpurun_out/r02p/bench
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02p/qkv -- python $R/tools/gemm_one.py 256 65792 4224 1408 20 > $R/gpurun_out/r02p/qkv.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02p/qkv -- python $R/tools/gemm_one.py 256 65792 4224 1408 200 > $R/gpurun_out/r02p/qkv.log 2>&1)
 find gpurun_out/r02p/qkv -name '*kernel_stats.csv' -exec cp {} gpurun_out/r02p/qkv_gemm256_kernel_stats.csv \;
 rm -rf gpurun_out/r02p/qkv
 timeout 600 bash tools/pmc_qkv.sh > gpurun_out/r02p/pmc_qkv.log 2>&1
