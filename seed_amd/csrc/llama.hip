@@ -30,8 +30,21 @@ struct SkinnyParams {
     bf16_t* xp_out;              // optional second copy of a BIAS_RESIDUAL result in the fragment-major activation layout
 };
 
+// stores of the persistent decode kernel's phase outputs: written through to memory (sc0 sc1), so that the other XCDs see them after
+// the grid barrier without anybody writing back a whole L2
+template <bool WT>
+SEEDMI_DEVINL void st_b64(bf16_t* ptr, uint2 v) {
+    if (WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+    else *(uint2*)ptr = v;
+}
+template <bool WT>
+SEEDMI_DEVINL void st_b16(bf16_t* ptr, bf16_t v) {
+    if (WT) asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(ptr), "v"((uint32_t)v) : "memory");
+    else *ptr = v;
+}
+
 // wave 0's epilogue: lane (li, g) owns rows m = 16 t + li and the four columns n0 + 16 r + 4 g .. +3
-template <int MT, int EPI, int R>
+template <int MT, int EPI, int R, bool WT = false>
 SEEDMI_DEVINL void skinny_epilogue(const SkinnyParams& p, f32x4 (&acc)[R][MT], int n0, int li, int g, const float (&rstd)[MT]) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -43,29 +56,36 @@ SEEDMI_DEVINL void skinny_epilogue(const SkinnyParams& p, f32x4 (&acc)[R][MT], i
         float v[4] = {acc[r][t][0] * rstd[t], acc[r][t][1] * rstd[t], acc[r][t][2] * rstd[t], acc[r][t][3] * rstd[t]};
         if (EPI == EPI_BIAS_RESIDUAL) {
             const bf16_t* rp = p.R + (size_t)m * p.ldr + nb_;
+            if (WT) {                                   // persistent kernel: x is re-written in place - read it past this CU's L1
+                uint2 rw;
+                asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(rw) : "v"(rp) : "memory");
+                v[0] = rbf(v[0]) + lo_bf(rw.x); v[1] = rbf(v[1]) + hi_bf(rw.x);
+                v[2] = rbf(v[2]) + lo_bf(rw.y); v[3] = rbf(v[3]) + hi_bf(rw.y);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) v[e] = rbf(v[e]) + bf2f(rp[e]);
+                for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) v[e] = rbf(v[e]) + bf2f(rp[e]);
+            }
         }
         if (EPI == EPI_SWIGLU) {
             const int kc = nb_ >> 1;                                     // output column of the first (gate, up) pair
             bf16_t* cp = p.c_packed
                 ? p.C + ((size_t)((m >> 4) * (p.N >> 6) + (kc >> 5)) * 64 + ((kc >> 3) & 3) * 16 + (m & 15)) * 8 + (kc & 7)
                 : p.C + (size_t)m * p.ldc + kc;
-            if (nb_ + 1 < p.N) cp[0] = f2bf(rbf(silu(rbf(v[0]))) * rbf(v[1]));
-            if (nb_ + 3 < p.N) cp[1] = f2bf(rbf(silu(rbf(v[2]))) * rbf(v[3]));
+            if (nb_ + 1 < p.N) st_b16<WT>(cp, f2bf(rbf(silu(rbf(v[0]))) * rbf(v[1])));
+            if (nb_ + 3 < p.N) st_b16<WT>(cp + 1, f2bf(rbf(silu(rbf(v[2]))) * rbf(v[3])));
         } else {
             bf16_t* cp = p.C + (size_t)m * p.ldc + nb_;
             if (nb_ + 4 <= p.N && (p.ldc % 4) == 0) {
                 uint2 w;
                 w.x = pack2bf(v[0], v[1]);
                 w.y = pack2bf(v[2], v[3]);
-                *(uint2*)cp = w;
+                st_b64<WT>(cp, w);
                 if (p.xp_out)                                             // the next GEMM's fragment-major A operand (row length N)
-                    *(uint2*)(p.xp_out + ((size_t)((m >> 4) * (p.N >> 5) + (nb_ >> 5)) * 64 + ((nb_ >> 3) & 3) * 16 + (m & 15)) * 8 +
-                              (nb_ & 7)) = w;
+                    st_b64<WT>(p.xp_out + ((size_t)((m >> 4) * (p.N >> 5) + (nb_ >> 5)) * 64 + ((nb_ >> 3) & 3) * 16 + (m & 15)) * 8 + (nb_ & 7),
+                               w);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) cp[e] = f2bf(v[e]);
+                for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) st_b16<WT>(cp + e, f2bf(v[e]));
             }
         }
     }
@@ -74,14 +94,14 @@ SEEDMI_DEVINL void skinny_epilogue(const SkinnyParams& p, f32x4 (&acc)[R][MT], i
 // NW waves split K; every wave keeps two register sets of U k-steps in flight (the next batch is requested before
 // the current one is consumed), i.e. up to 2*U*(1+MT) 16-byte loads per lane outstanding — what a one-workgroup-per-CU
 // launch (N/16 = 256 workgroups for the 4096-row projections) needs to cover HBM latency.
-template <int MT, int EPI, int NW, bool NT, bool PACKED, int R>
-__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
+template <int MT, int EPI, int NW, bool NT, bool PACKED, int R, bool WT = false>
+SEEDMI_DEVINL void skinny_tile(const SkinnyParams& p, const int bidx) {
     // R weight row-tiles (16 rows each) per workgroup share every activation fragment: the activation loads (16 rows x 64 B
     // gathers out of L2) cost more TA cycles than the weight stream itself, so R = 2 where N leaves enough workgroups.
     __shared__ float red[NW - 1][R][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = tid >> 6;
-    const int n0 = blockIdx.x * 16 * R;
+    const int n0 = bidx * 16 * R;
     const int kslice = p.K / NW;
     const int kbeg = wave * kslice;
     // PACKED: fragment-major weights (seedmi_pack_skinny_weights): tile j, k-step s is one contiguous 1 KiB block holding
@@ -91,7 +111,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int wrow = min(n0 + 16 * r + li, p.N - 1);
-        wp[r] = PACKED ? p.W + ((size_t)(blockIdx.x * R + r) * (p.K >> 5) + (kbeg >> 5)) * 512 + lane * 8
+        wp[r] = PACKED ? p.W + ((size_t)(bidx * R + r) * (p.K >> 5) + (kbeg >> 5)) * 512 + lane * 8
                        : p.W + (size_t)wrow * p.ldw + kbeg + 8 * g;
     }
     constexpr int WSTEP = PACKED ? 16 : 1;                           // element stride multiplier per k (32 k -> 512 elements)
@@ -178,27 +198,33 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
                 for (int e = 0; e < 4; ++e) red[wave - 1][r][t][lane][e] = acc[r][t][e];
     }
     __syncthreads();
-    if (wave != 0) return;
+    if (wave == 0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int w = 0; w < NW - 1; ++w)
+                for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[r][t][e] += red[w][r][t][lane][e];
-    float rstd[MT];
+                    for (int e = 0; e < 4; ++e) acc[r][t][e] += red[w][r][t][lane][e];
+        float rstd[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        rstd[t] = 1.f;
-        if (do_norm) {
-            float tot = 0.f;
+        for (int t = 0; t < MT; ++t) {
+            rstd[t] = 1.f;
+            if (do_norm) {
+                float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) tot += red_ss[w][t][li];        // fixed order: the same rstd in every workgroup
-            rstd[t] = rsqrtf(tot / (float)p.K + p.norm_eps);             // LlamaRMSNorm: variance = mean(x^2) in fp32 (llama_xformer.py:108-110)
+                for (int w = 0; w < NW; ++w) tot += red_ss[w][t][li];        // fixed order: the same rstd in every workgroup
+                rstd[t] = rsqrtf(tot / (float)p.K + p.norm_eps);             // LlamaRMSNorm: variance = mean(x^2) in fp32 (llama_xformer.py:108-110)
+            }
         }
+        skinny_epilogue<MT, EPI, R, WT>(p, acc, n0, li, g, rstd);
     }
-    skinny_epilogue<MT, EPI, R>(p, acc, n0, li, g, rstd);
+}
+
+template <int MT, int EPI, int NW, bool NT, bool PACKED, int R>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
+    skinny_tile<MT, EPI, NW, NT, PACKED, R>(p, (int)blockIdx.x);
 }
 
 int g_skinny_nt = 1, g_skinny_nw = 0;
@@ -354,23 +380,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 // key (same half-precision expression and rounding points as rope_kv_append_kernel, llama_xformer.py:147-168), stores the new
 // key / value row in the cache for the following steps, and attends over the cached rows plus the new one taken from
 // registers.  One launch per layer instead of two and no q round trip; results are bit-identical to the two-kernel form.
-__global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
-                                                               const long long* __restrict__ pos_ids,
-                                                               const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t,
-                                                               bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
-                                                               bf16_t* __restrict__ out, int ldo, int H, int tmax, int past_arg,
-                                                               float scale, int out_packed, int lds_len,
-                                                               const int* __restrict__ past_dev, int max_pos, int past_stride) {
-    extern __shared__ __attribute__((aligned(16))) float dsm[];
+// One (batch row, head) item of the fused decode attention, run by 256 threads (tid = 0..255) that share `dsm` (lds_len + 16 * 128
+// floats) and `wred` (4 floats).  Called by the stand-alone kernel (one item per workgroup) and by the persistent decode kernel (two
+// 256-thread halves of a workgroup, each with its own LDS slices; every thread of the workgroup reaches the four barriers whether its
+// half has an item (`active`) or not).
+template <bool WT = false>
+SEEDMI_DEVINL void attn_decode_item(const int item, const int tid, float* dsm, float* wred, const bool active,
+                                    const bf16_t* __restrict__ qkv, int ldqkv, const long long* __restrict__ pos_ids,
+                                    const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t, bf16_t* __restrict__ kc,
+                                    bf16_t* __restrict__ vc, bf16_t* __restrict__ out, int ldo, int H, int tmax, int past_arg, float scale,
+                                    int out_packed, int lds_len, const int* __restrict__ past_dev, int max_pos, int past_stride) {
     // (a graph replayed past the cache capacity keeps rewriting the last row instead of leaving the allocation)
     // past_stride 0: one cache length for the whole batch; 1: one per row (continuous batching: every slot at its own position)
-    const int past = past_dev ? min(past_dev[(blockIdx.x / H) * past_stride], tmax - 1) : past_arg;
-    const int kv_len = past + 1;
+    const int past = past_dev ? min(past_dev[(item / H) * past_stride], tmax - 1) : past_arg;
+    const int kv_len = active ? past + 1 : 0;                     // (an idle half walks the barriers with empty loops)
     float* sc = dsm;
     float* part = dsm + lds_len;
-    __shared__ float wred[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b = item / H, h = item % H;
     const int c = tid & 15;                         // 16-B chunk of the head dim: elements 8c .. 8c+7
     const int ks = tid >> 4;                        // key slot 0..15
     bf16_t* kb = kc + ((size_t)b * H + h) * tmax * DEC_HD;
@@ -379,8 +406,10 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
     pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);           // cos/sin tables have max_pos rows
     // rotate q and the new key: element i pairs with i +- 64, i.e. chunk c with chunk c ^ 8
     float qv[8], kn[8];
-    uint4 vnew;
-    {
+    uint4 vnew = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = kn[i] = 0.f;
+    if (active) {
         const bf16_t* row = qkv + (size_t)b * ldqkv + h * DEC_HD;
         const bool lo = c < 8;                      // first half: x*cos + (-partner)*sin ; second half: x*cos + partner*sin
         const uint4 uc = *(const uint4*)(cos_t + pos * DEC_HD + 8 * c);
@@ -411,6 +440,8 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
     // requested DU at a time before any of them is used: one exposed memory latency per DU rows instead of one per row (at ctx 123 the
     // un-batched loop was 8 dependent round trips for QK^T and 8 more for PV - most of this kernel's 20 us)
     constexpr int DU = 8;
+    // (requesting the first DU value rows together with the key rows - they do not depend on the softmax - was tried: 16.4 vs 14.4 us
+    // per launch at ctx 123; 116 instead of 78 VGPRs and twice the loads ahead of the first use)
     float lmax = -INFINITY;
     for (int j0 = ks; j0 < kv_len; j0 += 16 * DU) {
         uint4 kr[DU];
@@ -475,7 +506,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < 8; ++i) part[ks * DEC_HD + 8 * c + i] = o[i];
     __syncthreads();
-    if (tid < DEC_HD) {
+    if (active && tid < DEC_HD) {
         float a = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) a += part[s2 * DEC_HD + tid];
@@ -483,8 +514,21 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
         const size_t off = out_packed
             ? ((size_t)((b >> 4) * ((H * DEC_HD) >> 5) + (kcol >> 5)) * 64 + ((kcol >> 3) & 3) * 16 + (b & 15)) * 8 + (kcol & 7)
             : (size_t)b * ldo + kcol;
-        out[off] = f2bf(a);
+        st_b16<WT>(out + off, f2bf(a));
     }
+}
+
+__global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
+                                                               const long long* __restrict__ pos_ids,
+                                                               const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t,
+                                                               bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                               bf16_t* __restrict__ out, int ldo, int H, int tmax, int past_arg,
+                                                               float scale, int out_packed, int lds_len,
+                                                               const int* __restrict__ past_dev, int max_pos, int past_stride) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    __shared__ float wred[4];
+    attn_decode_item((int)blockIdx.x, (int)threadIdx.x, dsm, wred, true, qkv, ldqkv, pos_ids, cos_t, sin_t, kc, vc, out, ldo, H, tmax,
+                     past_arg, scale, out_packed, lds_len, past_dev, max_pos, past_stride);
 }
 
 // ------------------------------------------------------------------------------------------------ prefill attention
@@ -629,7 +673,114 @@ struct Carver {
         return r;
     }
 };
-struct LlamaWs { bf16_t *x, *xn, *qkv, *q, *att, *act; size_t bytes; };
+#ifdef SEEDMI_DEVTOOLS
+// ------------------------------------------------------------------------------------------------ persistent decode layers
+// (-DSEEDMI_DEVTOOLS build only: measured slower than one launch per phase, see DESIGN.md "persistent decode layers")
+// All decoder layers of one decode step (T == 1, M <= 32, folded RMSNorm, fragment-major operands) in ONE launch of one 512-thread
+// workgroup per CU.  Per layer five phases - [norm1 + QKV] -> [RoPE + append + attention] -> [o_proj + residual] -> [norm2 + gate/up +
+// SwiGLU] -> [down + residual] (llama_xformer.py:280-332) - separated by a grid barrier instead of a kernel boundary: the same tile
+// functions as the stand-alone kernels (skinny_tile, attn_decode_item), so the arithmetic of a step is bit-identical to the five-launch
+// form.  What the barrier buys over a kernel boundary: a workgroup issues the FIRST weight loads of its next phase before it waits
+// (weights do not depend on the previous phase; only the activations do), so the HBM stream does not restart from an empty pipeline
+// 160 times per 8B step.
+// Visibility: the phase outputs (qkv, att, xn, act) are written by one XCD and read by all.  They are stored write-through (sc0 sc1)
+// into buffers of their own PER LAYER, and every wave drains vmcnt before the barrier: an address that is written once per launch has
+// no stale copy in another XCD's L2 or in any L1, so no phase needs a cache invalidate (agent-scope release + acquire fences in every
+// wave cost 52 us per barrier - 2048 L2 write-backs; one acquiring wave per workgroup still 12 us - 32 L2 invalidates per XCD).
+// The residual stream x is the exception: re-written in place, but column block j is only ever touched by workgroup j (o_proj and
+// down use the same tiling), which reads it past its L1 (sc0).  The barrier is a
+// monotonic arrival counter in the workspace (zeroed by a memset node ahead of the launch), spins are bounded: a lost workgroup leaves
+// an error flag and wrong logits, not a hang.
+struct MegaLayer { const bf16_t *qkv_wp, *o_wp, *gu_wp, *down_wp; bf16_t *kc, *vc; };
+constexpr int MEGA_MAX_LAYERS = 64;
+struct MegaParams {
+    int M, h, F, H, tmax, max_pos, layers, past_stride, past_arg, lds_len;
+    int probe;                           // timing probes: 2 = barriers only, 3 = phases without barriers (results invalid)
+    float eps, scale;
+    bf16_t *x, *xn;                      // residual stream (row-major) and its fragment-major copy as layer 0 reads it
+    char* act_base;                      // per-layer buffers: [qkv | att | xn_mid | act | xn_out], act_stride bytes per layer
+    size_t act_stride;
+    const bf16_t *cos_t, *sin_t;
+    const long long* pos_ids;
+    const int* past_dev;
+    unsigned* bar;
+    MegaLayer layer[MEGA_MAX_LAYERS];
+};
+
+SEEDMI_DEVINL void grid_barrier(unsigned* bar, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's write-through stores have reached memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > (1 << 22)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+template <int MT>
+__global__ __launch_bounds__(512) void decode_layers_kernel(const MegaParams p) {
+    extern __shared__ __attribute__((aligned(16))) float mega_dsm[];
+    __shared__ float mega_wred[2][4];
+    const int tid = threadIdx.x, half = tid >> 8, tid2 = tid & 255;
+    const int G = gridDim.x;
+    unsigned phase = 0;
+    float* dsm_half = mega_dsm + half * (p.lds_len + 16 * DEC_HD);
+    SkinnyParams sp;
+    sp.M = p.M; sp.lda = 0; sp.ldw = 8; sp.a_packed = 1;
+    const size_t Mp = (size_t)((p.M + 15) / 16 * 16);
+    const bf16_t* xn_in = p.xn;
+    for (int l = 0; l < p.layers; ++l) {
+        const MegaLayer& L = p.layer[l];
+        bf16_t* const qkv = (bf16_t*)(p.act_base + (size_t)l * p.act_stride);
+        bf16_t* const att = qkv + Mp * 3 * p.h;
+        bf16_t* const xn_mid = att + Mp * p.h;
+        bf16_t* const act = xn_mid + Mp * p.h;
+        bf16_t* const xn_out = act + Mp * p.F;
+        // ---- input_layernorm + q/k/v projections (llama_xformer.py:298-299, 223-225)
+        sp.N = 3 * p.h; sp.K = p.h; sp.A = xn_in; sp.W = L.qkv_wp; sp.R = nullptr; sp.ldr = 0; sp.C = qkv; sp.ldc = 3 * p.h;
+        sp.c_packed = 0; sp.norm_eps = p.eps; sp.xp_out = nullptr;
+        for (int j = blockIdx.x; j < sp.N / 48 && p.probe != 2; j += G) { skinny_tile<MT, EPI_NONE, 8, true, true, 3, true>(sp, j); __syncthreads(); }
+        if (p.probe != 3) grid_barrier(p.bar, ++phase * G);
+        // ---- rotary embedding, cache append, attention over the cache (llama_xformer.py:228-256)
+        {
+            const int items = p.M * p.H;
+            for (int i0 = 2 * blockIdx.x; i0 < items && p.probe != 2; i0 += 2 * G) {
+                const int item = i0 + half;
+                const bool active = item < items;
+                attn_decode_item<true>(active ? item : 0, tid2, dsm_half, mega_wred[half], active, qkv, 3 * p.h, p.pos_ids, p.cos_t, p.sin_t,
+                                       L.kc, L.vc, att, p.h, p.H, p.tmax, p.past_arg, p.scale, 1, p.lds_len, p.past_dev, p.max_pos,
+                                       p.past_stride);
+                __syncthreads();                                   // (the LDS slices are reused by the next item)
+            }
+        }
+        if (p.probe != 3) grid_barrier(p.bar, ++phase * G);
+        // ---- o_proj + residual (llama_xformer.py:258, 316); also writes the fragment-major copy of the new residual stream
+        sp.N = p.h; sp.K = p.h; sp.A = att; sp.W = L.o_wp; sp.R = p.x; sp.ldr = p.h; sp.C = p.x; sp.ldc = p.h; sp.c_packed = 0;
+        sp.norm_eps = 0.f; sp.xp_out = xn_mid;
+        for (int j = blockIdx.x; j < sp.N / 16 && p.probe != 2; j += G) { skinny_tile<MT, EPI_BIAS_RESIDUAL, 8, true, true, 1, true>(sp, j); __syncthreads(); }
+        if (p.probe != 3) grid_barrier(p.bar, ++phase * G);
+        // ---- post_attention_layernorm + gate/up + SwiGLU (llama_xformer.py:320-321, 186)
+        sp.N = 2 * p.F; sp.K = p.h; sp.A = xn_mid; sp.W = L.gu_wp; sp.R = nullptr; sp.ldr = 0; sp.C = act; sp.ldc = p.F; sp.c_packed = 1;
+        sp.norm_eps = p.eps; sp.xp_out = nullptr;
+        for (int j = blockIdx.x; j < sp.N / 32 && p.probe != 2; j += G) { skinny_tile<MT, EPI_SWIGLU, 8, true, true, 2, true>(sp, j); __syncthreads(); }
+        if (p.probe != 3) grid_barrier(p.bar, ++phase * G);
+        // ---- down_proj + residual (llama_xformer.py:186, 322)
+        sp.N = p.h; sp.K = p.F; sp.A = act; sp.W = L.down_wp; sp.R = p.x; sp.ldr = p.h; sp.C = p.x; sp.ldc = p.h; sp.c_packed = 0;
+        sp.norm_eps = 0.f; sp.xp_out = (l + 1 < p.layers) ? xn_out : p.xn;           // (the last layer's copy is what lm_head reads)
+        for (int j = blockIdx.x; j < sp.N / 16 && p.probe != 2; j += G) { skinny_tile<MT, EPI_BIAS_RESIDUAL, 8, true, true, 1, true>(sp, j); __syncthreads(); }
+        if (p.probe != 3) grid_barrier(p.bar, ++phase * G);
+        xn_in = xn_out;
+    }
+}
+
+int g_decode_mega = 0;               // seedmi_set_option("decode_persistent", 0|1): all layers of a decode step in one persistent launch
+#endif
+
+struct LlamaWs { bf16_t *x, *xn, *qkv, *q, *att, *act; unsigned* bar; bf16_t* mega; size_t mega_stride; size_t bytes; };
 LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     const size_t M = (size_t)B * T, h = w->hidden, F = w->ffn;
     const size_t Mp = (M + 15) / 16 * 16;            // fragment-major buffers hold whole 16-row tiles
@@ -641,9 +792,68 @@ LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     t.q = (bf16_t*)c.take(M * h * 2);
     t.att = (bf16_t*)c.take(Mp * h * 2);
     t.act = (bf16_t*)c.take(Mp * F * 2);
+    t.bar = (unsigned*)c.take(256);                  // persistent decode kernel: arrival counter, error flag
+    // ... and its per-layer activation buffers (qkv | att | xn after o_proj | act | xn after down), decode steps only: a buffer that
+    // is written once per launch never has a stale copy in another XCD's L2, so no phase needs a cache invalidate
+    t.mega_stride = 0;
+    t.mega = nullptr;
+#ifdef SEEDMI_DEVTOOLS
+    if (T == 1 && M <= 32) {
+        t.mega_stride = (Mp * (3 * h + h + h + F + h) * 2 + 255) / 256 * 256;
+        t.mega = (bf16_t*)c.take(t.mega_stride * (size_t)w->layers);
+    }
+#endif
     t.bytes = c.off;
     return t;
 }
+
+
+#ifdef SEEDMI_DEVTOOLS
+// host side of decode_layers_kernel; returns SEEDMI_OK + *done = 1 when it ran, *done = 0 when the shape is not covered (caller falls
+// back to one launch per phase)
+int decode_layers_launch(const seedmi_llama_weights_t* w, const LlamaWs& t, int batch, const void* pos_i64, int past_len,
+                         const void* past_len_dev, int past_stride, float scale, hipStream_t stream, int* done) {
+    *done = 0;
+    const int h = w->hidden, F = w->ffn, H = w->heads;
+    // (the shapes for which the stand-alone launcher picks the same tiling: 8-way K split, 48 / 16 / 32 / 16 weight rows per tile)
+    if (!g_decode_mega || !t.mega || batch > 32 || w->layers > MEGA_MAX_LAYERS || h / H != DEC_HD || (3 * h) % 48 || (2 * F) % 32 || h % 16 ||
+        (h % 256) || h < 2048 || (F % 256) || F < 2048 || g_skinny_nw == 4 || g_skinny_r != 0 || !g_skinny_nt)
+        return SEEDMI_OK;
+    const int lds_len = ((past_len_dev ? w->tmax : past_len + 1) + 3) & ~3;
+    const size_t dyn = 2 * (size_t)(lds_len + 16 * DEC_HD) * sizeof(float);
+    if (dyn > 60 * 1024) return SEEDMI_OK;
+    MegaParams p;
+    p.M = batch; p.h = h; p.F = F; p.H = H; p.tmax = w->tmax; p.max_pos = w->max_pos; p.layers = w->layers; p.past_stride = past_stride;
+    p.past_arg = past_len; p.lds_len = lds_len; p.eps = w->rms_eps; p.scale = scale; p.probe = g_decode_mega;
+    p.x = t.x; p.xn = t.xn; p.act_base = (char*)t.mega; p.act_stride = t.mega_stride;
+    p.cos_t = (const bf16_t*)w->cos_t; p.sin_t = (const bf16_t*)w->sin_t;
+    p.pos_ids = past_len_dev ? nullptr : (const long long*)pos_i64;
+    p.past_dev = (const int*)past_len_dev;
+    p.bar = t.bar;
+    for (int l = 0; l < w->layers; ++l) {
+        const seedmi_llama_layer_t& L = w->layer[l];
+        p.layer[l] = {(const bf16_t*)L.qkv_wp, (const bf16_t*)L.o_wp, (const bf16_t*)L.gate_up_wp, (const bf16_t*)L.down_wp, (bf16_t*)L.k_cache,
+                      (bf16_t*)L.v_cache};
+    }
+    if (hipMemsetAsync(t.bar, 0, 256, stream) != hipSuccess) {
+        seedmi_set_error("seedmi_llama_forward: clearing the decode barrier failed");
+        return SEEDMI_E_HIP;
+    }
+    const int dev = seedmi_current_device();
+    const int grid = seedmi_device_cus(dev);
+    static bool attr_set[2][SEEDMI_MAX_DEVICES] = {};
+    const int mt = (batch + 15) / 16;
+    if (!attr_set[mt - 1][dev]) {
+        if (mt == 1) (void)hipFuncSetAttribute((const void*)decode_layers_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        else (void)hipFuncSetAttribute((const void*)decode_layers_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        attr_set[mt - 1][dev] = true;
+    }
+    if (mt == 1) hipLaunchKernelGGL(decode_layers_kernel<1>, dim3(grid), dim3(512), dyn, stream, p);
+    else hipLaunchKernelGGL(decode_layers_kernel<2>, dim3(grid), dim3(512), dyn, stream, p);
+    *done = 1;
+    return seedmi_check_launch("decode_layers");
+}
+#endif
 
 #define CK(call)                          \
     do {                                  \
@@ -864,6 +1074,9 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
     if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
+#ifdef SEEDMI_DEVTOOLS
+    if (!strcmp(key, "decode_persistent") && (value >= 0 && value <= 3)) { g_decode_mega = value; return SEEDMI_OK; }
+#endif
     if (!strcmp(key, "prefill_tiled") && (value == 0 || value == 1)) { g_prefill_tiled = value; return SEEDMI_OK; }
     if (!strcmp(key, "decode_ablate_norm") && (value == 0 || value == 1)) { g_ablate_norm = value; return SEEDMI_OK; }
     return SEEDMI_E_SHAPE;
@@ -1136,7 +1349,12 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
     // residual stream also writes its fragment-major copy - no norm launches, no extra pass over x (64 launches per 8B step)
     const bool fold = pk && w->norm_folded && !g_ablate_norm;
     if (fold) CK(seedmi_pack_activations_bf16(t.x, h, t.xn, M, h, stream));
-    for (int l = 0; l < w->layers; ++l) {
+    int mega_done = 0;
+#ifdef SEEDMI_DEVTOOLS
+    if (fold && g_decode_fused && !hidden_states)
+        CK(decode_layers_launch(w, t, batch, pos_i64, past_len, past_len_dev, past_stride, scale, (hipStream_t)stream, &mega_done));
+#endif
+    for (int l = 0; l < w->layers && !mega_done; ++l) {
         const seedmi_llama_layer_t& L = w->layer[l];
         CK(tap_hidden(l, t.x));
         if (fold) {

@@ -187,6 +187,46 @@ def test_llama8b_width_parity_with_oracle(fold_norm):
     print(f"[8B-width greedy fold={fold_norm}] token agreement {same.float().mean().item():.3f}, confident {confident.float().mean().item():.3f}")
 
 
+def test_persistent_decode_layers_are_bit_identical():
+    """Devtools build, seedmi_set_option("decode_persistent", 1): all decoder layers of a decode step in one persistent launch (grid barriers instead of
+    kernel boundaries, llama_xformer.py:280-332 per layer).  Same tile functions as the per-phase launches, so logits, the KV cache and
+    the greedy tokens of the eager loop and of the hipGraph replay must be EQUAL, at 8B width (2 layers, B = 32)."""
+    from dataclasses import replace
+    from seed_amd import lib as L
+    lib = L.load()
+    if lib.seedmi_set_option(b"decode_persistent", 0) != 0:
+        pytest.skip("the persistent decode kernel lives in the devtools build (SEEDMI_LIB_PATH=seed_amd/libseedmi_dev.so): measured slower")
+    cfg = replace(C.LLAMA_8B, layers=2)
+    sd = make_llama_state_dict(cfg, seed=3, dtype=torch.bfloat16, norm_jitter=0.05)
+    B, T0, n_new = 32, 21, 7
+    prompt = torch.randint(3, 32000, (B, T0), generator=torch.Generator().manual_seed(5)).cuda()
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=64)
+    out = {}
+    try:
+        for mode in (0, 1):
+            L.check(lib.seedmi_set_option(b"decode_persistent", mode), "opt")
+            eng.reset()
+            lg = eng.forward(prompt, last_only=True)
+            steps = [lg[:, 0].clone()]
+            tok = lg[:, 0].float().argmax(-1, keepdim=True)
+            for _ in range(4):
+                lg = eng.forward(tok, last_only=True)
+                steps.append(lg[:, 0].clone())
+                tok = lg[:, 0].float().argmax(-1, keepdim=True)
+            torch.cuda.synchronize()
+            kc = eng.k_cache[1][:B, :, :T0 + 4].clone()
+            vc = eng.v_cache[0][:B, :, :T0 + 4].clone()
+            eager, _ = eng.greedy_decode(prompt, n_new)
+            graphed = eng.greedy_decode_graph(prompt, n_new).clone()
+            torch.cuda.synchronize()
+            out[mode] = (torch.stack(steps), kc, vc, eager.clone(), graphed)
+    finally:
+        lib.seedmi_set_option(b"decode_persistent", 0)
+    for a, b, what in zip(out[0], out[1], ("logits", "k cache", "v cache", "eager tokens", "graph tokens")):
+        assert torch.equal(a, b), what
+    assert torch.equal(out[1][3], out[1][4])
+
+
 def test_replay_beyond_the_captured_steps_is_refused():
     """replay(k) past the capture's capacity would index the cache / uniforms / out by an unchecked device counter."""
     from seed_amd import lib as L

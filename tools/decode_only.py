@@ -12,6 +12,10 @@ from seed_amd import config as C  # noqa: E402
 from seed_amd.llama_engine import LlamaEngine  # noqa: E402
 from seed_amd.weights import make_llama_state_dict  # noqa: E402
 
+from seed_amd import lib as L  # noqa: E402
+for kv in [x for x in os.environ.get("DECODE_OPTS", "").split(",") if x]:      # e.g. DECODE_OPTS="decode_persistent=1"
+    k, v = kv.split("=")
+    L.check(L.load().seedmi_set_option(k.encode(), int(v)), kv)
 cfg = C.LLAMA_8B
 sd = make_llama_state_dict(cfg, seed=0, device="cuda", dtype=torch.bfloat16)
 eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=32, tmax=256)
