@@ -51,7 +51,8 @@ int seedmi_check_device(void);
  * many tiles), "tokenize_streams" (1..4 concurrent sub-batches inside seedmi_tokenize), "tokenize_streamk" (0|1: stream-K
  * tail for the tokenizer's big GEMMs, default 0), "tokenize_lnfold" (0|1: LayerNorm folded into qkv / fc1 when the weights carry
  * the folded copies, default 1), "tokenize_split_rounds" (0|1: a big GEMM whose 256x256 tiles overshoot a whole number of rounds by
- * a few m-tiles runs those rows as a second, 128x128-tiled call; pays on one stream only, default 0), "skinny_nt" / "skinny_waves" / "skinny_rows"
+ * a few m-tiles runs those rows as a second, 128x128-tiled call; pays on one stream only, default 0), "tokenize_vq_head" (0|1: the head's last Linear fused into the VQ argmin kernel, default 1),
+ * "skinny_nt" / "skinny_waves" / "skinny_rows"
  * (decode GEMM), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
  * (attention kernel selection).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
@@ -136,6 +137,11 @@ int seedmi_vq_code_sqnorm(const void* codebook, void* ee_f32, int n_embed, int d
  * int64 output.  dim must be 32. */
 int seedmi_vq_argmin_bf16(const void* z, int ldz, const void* codebook, const void* ee_f32, void* ids_i64, int rows,
                           int n_embed, int dim, void* stream);
+/* encode_task_layer's last Linear (qformer_quantizer.py:219-223, Linear(hidden, 32) after the Tanh) fused in front of the argmin
+ * (SURVEY 8a a13 -> a14): t [rows, hidden] bf16 = the Tanh output, w [32, hidden], bias [32] (may be NULL); z = half(t w^T + bias) goes
+ * into the sweep from LDS and, when z_out != NULL, to z_out [rows, 32] (row stride ldz).  hidden % 8 == 0, hidden <= 1024. */
+int seedmi_vq_head_argmin_bf16(const void* t, int ldt, int hidden, const void* w, int ldw, const void* bias, const void* codebook,
+                               const void* ee_f32, void* ids_i64, void* z_out, int ldz, int rows, int n_embed, int dim, void* stream);
 
 /* ---- LLaMA pieces ---------------------------------------------------------------------------------------------- */
 /* nn.Embedding gather (llama_xformer.py:544): out[i,:] = table[ids[i],:]. */

@@ -1122,6 +1122,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
     if (key && !strcmp(key, "tokenize_streamk") && seedmi_tokenizer_set_streamk(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_lnfold") && seedmi_tokenizer_set_lnfold(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_split_rounds") && seedmi_tokenizer_set_split(value) == SEEDMI_OK) return SEEDMI_OK;
+    if (key && !strcmp(key, "tokenize_vq_head") && seedmi_tokenizer_set_vqhead(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_llama_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_attn_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);

@@ -38,6 +38,7 @@ struct TokWs {
 
 int g_tok_streamk = 0;                    // seedmi_set_option("tokenize_streamk", 0|1)
 int g_tok_split = 0;                      // seedmi_set_option("tokenize_split_rounds", 0|1): whole rounds of 256x256 tiles + a 128x128 remainder
+int g_tok_vqhead = 1;                     // seedmi_set_option("tokenize_vq_head", 0|1): last head Linear fused into the VQ argmin kernel
 int g_tok_lnfold = 1;                     // seedmi_set_option("tokenize_lnfold", 0|1): LayerNorm folded into qkv / fc1 when the weights carry it
 
 TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
@@ -233,6 +234,12 @@ int run_phase(const Part& p, int phase) {
     const int cd = w->code_dim;
     if (p.taps.qformer_out) HIPCK(hipMemcpyAsync(p.taps.qformer_out, t.qx, (size_t)Mq * Q * 2, hipMemcpyDeviceToDevice, p.s));
     CK(seedmi_gemm_bf16(Mq, Q, Q, t.qx, Q, w->head_w0, Q, w->head_b0, nullptr, 0, SEEDMI_EPI_BIAS_TANH, t.qa, Q, 0, 0, s));
+    if (g_tok_vqhead && Q <= 1024 && (Q % 8) == 0) {
+        // Linear(768, 32) fused in front of the argmin: z reaches the sweep from LDS (and the tap, if asked for, from the same kernel)
+        CK(seedmi_vq_head_argmin_bf16(t.qa, Q, Q, w->head_w1, Q, w->head_b1, w->codebook, w->code_sqnorm, p.ids, p.taps.z, cd, Mq, w->n_embed, cd,
+                                      s));
+        return SEEDMI_OK;
+    }
     CK(seedmi_gemm_bf16(Mq, cd, Q, t.qa, Q, w->head_w1, Q, w->head_b1, nullptr, 0, SEEDMI_EPI_BIAS, t.z, cd, 0, 0, s));
     if (p.taps.z) HIPCK(hipMemcpyAsync(p.taps.z, t.z, (size_t)Mq * cd * 2, hipMemcpyDeviceToDevice, p.s));
     CK(seedmi_vq_argmin_bf16(t.z, cd, w->codebook, w->code_sqnorm, p.ids, Mq, w->n_embed, cd, s));
@@ -301,6 +308,11 @@ int seedmi_tokenizer_set_lnfold(int v) {
 int seedmi_tokenizer_set_split(int v) {
     if (v != 0 && v != 1) return SEEDMI_E_SHAPE;
     g_tok_split = v;
+    return SEEDMI_OK;
+}
+int seedmi_tokenizer_set_vqhead(int v) {
+    if (v != 0 && v != 1) return SEEDMI_E_SHAPE;
+    g_tok_vqhead = v;
     return SEEDMI_OK;
 }
 int seedmi_tokenizer_set_streamk(int v) {

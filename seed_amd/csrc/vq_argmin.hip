@@ -34,21 +34,14 @@ __global__ __launch_bounds__(256) void vq_code_sqnorm_kernel(const bf16_t* __res
     ee[i] = rbf(acc);                            // torch.sum(...) output in the model dtype
 }
 
-__global__ __launch_bounds__(256) void vq_argmin_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ cb,
-                                                        const float* __restrict__ ee, long long* __restrict__ out,
-                                                        int rows, int n_embed) {
-    __shared__ __attribute__((aligned(16))) float zs[VQ_ROWS][VQ_D];
+// the sweep: zs holds the workgroup's VQ_ROWS rows of z (fp32 copies of half values), filled by the caller
+SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __restrict__ cb, const float* __restrict__ ee,
+                            long long* __restrict__ out, int rows, int n_embed) {
     __shared__ float zz_s[VQ_ROWS];
     __shared__ float red_d[4][VQ_ROWS];
     __shared__ int red_i[4][VQ_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * VQ_ROWS;
-
-    for (int idx = tid; idx < VQ_ROWS * VQ_D; idx += 256) {
-        const int r = idx / VQ_D, k = idx - r * VQ_D;
-        const int row = min(row0 + r, rows - 1);
-        zs[r][k] = bf2f(z[(size_t)row * ldz + k]);
-    }
     __syncthreads();
     if (tid < VQ_ROWS) {
         float acc = 0.f;
@@ -113,6 +106,60 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const bf16_t* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ cb,
+                                                        const float* __restrict__ ee, long long* __restrict__ out,
+                                                        int rows, int n_embed) {
+    __shared__ __attribute__((aligned(16))) float zs[VQ_ROWS][VQ_D];
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * VQ_ROWS;
+    for (int idx = tid; idx < VQ_ROWS * VQ_D; idx += 256) {
+        const int r = idx / VQ_D, k = idx - r * VQ_D;
+        const int row = min(row0 + r, rows - 1);
+        zs[r][k] = bf2f(z[(size_t)row * ldz + k]);
+    }
+    vq_sweep(zs, cb, ee, out, rows, n_embed);
+}
+
+// encode_task_layer's second Linear (qformer_quantizer.py:219-223: Linear(768, 32) after the Tanh) fused in front of the sweep
+// (SURVEY 8a a13 -> a14): the workgroup's VQ_ROWS rows of the tanh output are staged in LDS, thread (r, k) = (tid / 32, tid % 32) forms
+// z[r][k] = half(sum_j t[r][j] w[k][j] + b[k]) with a sequential fp32 chain, z goes straight into the sweep's LDS copy and, when asked
+// for (taps), to memory.  No [rows, 32] round trip, no 32-column launch of a 128-column GEMM tile.
+constexpr int VQ_HMAX = 1024;                    // widest hidden size staged (Q-Former: 768)
+__global__ __launch_bounds__(256) void vq_head_argmin_kernel(const bf16_t* __restrict__ t, int ldt, int hidden, const bf16_t* __restrict__ w1,
+                                                             int ldw, const bf16_t* __restrict__ b1, const bf16_t* __restrict__ cb,
+                                                             const float* __restrict__ ee, long long* __restrict__ out,
+                                                             bf16_t* __restrict__ z_out, int ldz, int rows, int n_embed) {
+    __shared__ __attribute__((aligned(16))) float zs[VQ_ROWS][VQ_D];
+    __shared__ __attribute__((aligned(16))) bf16_t ts[VQ_ROWS][VQ_HMAX];
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * VQ_ROWS;
+    const int chunks = hidden >> 3;
+    for (int idx = tid; idx < VQ_ROWS * chunks; idx += 256) {
+        const int r = idx / chunks, c = idx - r * chunks;
+        const int row = min(row0 + r, rows - 1);
+        *(uint4*)&ts[r][8 * c] = *(const uint4*)(t + (size_t)row * ldt + 8 * c);
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 5, k = tid & 31;
+        const bf16_t* wr = w1 + (size_t)k * ldw;
+        float acc = 0.f;
+        for (int c = 0; c < chunks; ++c) {
+            const uint4 wv = *(const uint4*)(wr + 8 * c), tv = *(const uint4*)&ts[r][8 * c];
+            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w}, tw[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc = __builtin_fmaf(lo_bf(tw[i]), lo_bf(ww[i]), acc);
+                acc = __builtin_fmaf(hi_bf(tw[i]), hi_bf(ww[i]), acc);
+            }
+        }
+        const bf16_t zh = f2bf(acc + (b1 ? bf2f(b1[k]) : 0.f));
+        zs[r][k] = bf2f(zh);
+        if (z_out && row0 + r < rows) z_out[(size_t)(row0 + r) * ldz + k] = zh;
+    }
+    vq_sweep(zs, cb, ee, out, rows, n_embed);
+}
+
 }  // namespace
 
 extern "C" int seedmi_vq_code_sqnorm(const void* codebook, void* ee_f32, int n_embed, int dim, void* stream) {
@@ -139,4 +186,22 @@ extern "C" int seedmi_vq_argmin_bf16(const void* z, int ldz, const void* codeboo
                        (const bf16_t*)z, ldz, (const bf16_t*)codebook, (const float*)ee_f32, (long long*)ids_i64, rows,
                        n_embed);
     return seedmi_check_launch("vq_argmin");
+}
+
+extern "C" int seedmi_vq_head_argmin_bf16(const void* t, int ldt, int hidden, const void* w, int ldw, const void* bias, const void* codebook,
+                                          const void* ee_f32, void* ids_i64, void* z_out, int ldz, int rows, int n_embed, int dim,
+                                          void* stream) {
+    if (dim != VQ_D || rows <= 0 || n_embed <= 0 || hidden <= 0 || hidden > VQ_HMAX || (hidden % 8) || (ldt % 8) || (ldw % 8)) {
+        seedmi_set_error("seedmi_vq_head_argmin_bf16: rows=%d n_embed=%d dim=%d (must be %d) hidden=%d (multiple of 8, <= %d)", rows, n_embed, dim,
+                         VQ_D, hidden, VQ_HMAX);
+        return SEEDMI_E_SHAPE;
+    }
+    if ((((uintptr_t)codebook | (uintptr_t)t | (uintptr_t)w) & 15)) {
+        seedmi_set_error("seedmi_vq_head_argmin_bf16: t, w and the codebook must be 16-byte aligned");
+        return SEEDMI_E_ALIGN;
+    }
+    hipLaunchKernelGGL(vq_head_argmin_kernel, dim3((rows + VQ_ROWS - 1) / VQ_ROWS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, ldt,
+                       hidden, (const bf16_t*)w, ldw, (const bf16_t*)bias, (const bf16_t*)codebook, (const float*)ee_f32, (long long*)ids_i64,
+                       (bf16_t*)z_out, ldz, rows, n_embed);
+    return seedmi_check_launch("vq_head_argmin");
 }

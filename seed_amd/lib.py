@@ -85,6 +85,7 @@ SIGNATURES = {
     "seedmi_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.c_float, _i, _i, _vp]),
     "seedmi_vq_code_sqnorm": (_i, [_vp, _vp, _i, _i, _vp]),
     "seedmi_vq_argmin_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "seedmi_vq_head_argmin_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "seedmi_embed_rows": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "seedmi_rope_kv_append": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "seedmi_add_i32": (_i, [_vp, _i, _vp]),

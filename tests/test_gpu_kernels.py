@@ -435,6 +435,39 @@ def test_vq_argmin_bit_exact(lib, golden_dir):
     assert (ids_small != ref_ids).float().mean() <= 0.02
 
 
+def test_vq_head_argmin_fused(lib):
+    """seedmi_vq_head_argmin_bf16 (SURVEY 8a a13 -> a14): Linear(768, 32) + bias of encode_task_layer (qformer_quantizer.py:219-223) fused in
+    front of the VQ sweep.  z equals the fp64 Linear rounded to half on all but a handful of round-to-nearest ties of the fp32 chain, and the
+    ids are EXACTLY the oracle's argmin of the z the kernel itself produced (ragged row count)."""
+    from oracle import seed_oracle as O
+    gen = torch.Generator().manual_seed(21)
+    rows, hidden, n_embed = 1003, 768, 8192
+    t = bf(torch.tanh(rand(gen, rows, hidden)))
+    w = bf(rand(gen, 32, hidden, scale=0.05))
+    b = bf(rand(gen, 32, scale=0.1))
+    cb = bf(rand(gen, n_embed, 32, scale=0.35))
+    td, wd, bd, cbd = t.cuda(), w.cuda(), b.cuda(), cb.cuda()
+    ee = torch.empty(n_embed, dtype=torch.float32, device="cuda")
+    ids = torch.full((rows,), -1, dtype=torch.int64, device="cuda")
+    z = torch.zeros(rows, 32, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.seedmi_vq_code_sqnorm(L.ptr(cbd), L.ptr(ee), n_embed, 32, L.stream_ptr()), "sqnorm")
+    L.check(lib.seedmi_vq_head_argmin_bf16(L.ptr(td), hidden, hidden, L.ptr(wd), hidden, L.ptr(bd), L.ptr(cbd), L.ptr(ee), L.ptr(ids), L.ptr(z), 32,
+                                           rows, n_embed, 32, L.stream_ptr()), "vq head")
+    ids2 = torch.full((rows,), -1, dtype=torch.int64, device="cuda")
+    L.check(lib.seedmi_vq_head_argmin_bf16(L.ptr(td), hidden, hidden, L.ptr(wd), hidden, L.ptr(bd), L.ptr(cbd), L.ptr(ee), L.ptr(ids2), None, 0,
+                                           rows, n_embed, 32, L.stream_ptr()), "vq head, no tap")
+    torch.cuda.synchronize()
+    want_z = r((t.double() @ w.double().t() + b.double()).float())
+    zc = z.float().cpu()
+    exact = (zc == want_z).float().mean().item()
+    print(f"[vq head] z equal to the fp64 Linear rounded to half: {exact:.5f}")
+    assert exact > 0.995
+    assert_close_bf16(z, want_z, "vq head z", atol_ulps=1.01, frac=1.0)
+    want_ids = O.vq_argmin(zc, cb.float(), O.Prec("bf16"))
+    assert torch.equal(ids.cpu(), want_ids)
+    assert torch.equal(ids2.cpu(), want_ids)
+
+
 def test_vq_codebook_sqnorm_exact(lib):
     from oracle import seed_oracle as O
     gen = torch.Generator().manual_seed(9)
