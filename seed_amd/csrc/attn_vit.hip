@@ -36,6 +36,9 @@ struct VitAttnParams {
     int ldq, ldk, ldv, ldo;
     int n, heads, items;
     float scale;
+#ifdef SEEDMI_DEVTOOLS
+    unsigned long long* dbg;      // phase clock stamps of workgroup 0 (tools/attn_phase_times.py): [wave][item][6]
+#endif
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -101,12 +104,23 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
     stage(p.V, p.ldv, Vsm, item);
     const float L2E = 1.4426950408889634f;
 
+#ifdef SEEDMI_DEVTOOLS
+    int dbg_it = 0;
+#define VSTAMP(k_)                                                                                                     \
+    do {                                                                                                               \
+        if (p.dbg && blockIdx.x == 0 && lane == 0 && dbg_it < 8) p.dbg[(wave * 8 + dbg_it) * 6 + (k_)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define VSTAMP(k_) do {} while (0)
+#endif
     for (;;) {
         const int b = item / p.heads, h = item - b * p.heads;
+        VSTAMP(0);
         // ---- K(item), Q(item) landed everywhere (only this wave's V pieces may still be in flight)
         wait_vm(my_pieces);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        VSTAMP(1);
 
         // ---- S^T = K Q^T and softmax per q-tile; P packed to bf16 MFMA operands and kept in registers
         bf16x8 pf[VMAXT][VKK];
@@ -210,10 +224,12 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
             }
         }
 
+        VSTAMP(2);
         // ---- V(item) landed; every wave is done with K(item) and Q(item)
         wait_vm(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        VSTAMP(3);
         const int next = item + gridDim.x;
         const bool more = next < p.items;
         if (more) {
@@ -270,17 +286,29 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
                 }
             }
         }
+        VSTAMP(4);
         if (!more) break;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                              // every wave is done with V(item)
+        VSTAMP(5);
+#ifdef SEEDMI_DEVTOOLS
+        ++dbg_it;
+#endif
         stage(p.V, p.ldv, Vsm, next);
         item = next;
     }
 }
 
 int g_attn_vit = 1;
+#ifdef SEEDMI_DEVTOOLS
+unsigned long long* g_attn_dbg = nullptr;
+#endif
 
 }  // namespace
+#ifdef SEEDMI_DEVTOOLS
+// devtools: device buffer of 12 x 8 x 6 uint64 that workgroup 0 of the next ViT attention launches fills with phase clock stamps
+extern "C" int seedmi_attn_vit_timing(void* buf) { g_attn_dbg = (unsigned long long*)buf; return SEEDMI_OK; }
+#endif
 
 int seedmi_attn_vit_enabled() { return g_attn_vit; }
 int seedmi_attn_vit_set(int v) { g_attn_vit = v; return SEEDMI_OK; }
@@ -294,6 +322,9 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.n = nq; p.heads = heads; p.items = batch * heads; p.scale = scale;
+#ifdef SEEDMI_DEVTOOLS
+    p.dbg = g_attn_dbg;
+#endif
     const int dev = seedmi_current_device();
     const int n_cu = seedmi_device_cus(dev);
     const int grid = p.items < n_cu ? p.items : n_cu;
