@@ -47,7 +47,7 @@ int seedmi_check_device(void);
 /* Tuning overrides: PROCESS-WIDE selections between kernels that compute the same result (relaxed atomics: reads are race-free,
  * but they are not part of the per-stream thread-safety contract - set them before concurrent use; production callers leave the
  * defaults).  Keys (value): "gemm" (0 automatic | 128 | 256), "gemm_persist" (0|1), "gemm_streamk" (0|1: stream-K tail when a
- * workspace is passed), "gemm_group_m" (1..64 m-tiles per L2 tile group), "gemm_min_tiles" (256x256 kernel only at or above this
+ * workspace is passed), "gemm_group_m" (1..64 m-tiles per L2 tile group, 0 = chosen by shape: the default), "gemm_min_tiles" (256x256 kernel only at or above this
  * many tiles), "tokenize_streams" (1..4 concurrent sub-batches inside seedmi_tokenize), "tokenize_streamk" (0|1: stream-K
  * tail for the tokenizer's big GEMMs, default 0), "tokenize_lnfold" (0|1: LayerNorm folded into qkv / fc1 when the weights carry
  * the folded copies, default 1), "tokenize_split_rounds" (0|1: a big GEMM whose 256x256 tiles overshoot a whole number of rounds by

@@ -44,7 +44,7 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A tile + W tile
 #ifdef SEEDMI_DEVTOOLS
 std::atomic<int> g_gemm_ablate{0};   // "gemm_ablate": timing-only ablations (devtools build only)
 #endif
-std::atomic<int> g_group_m{4};       // "gemm_group_m": m-tiles per L2 tile group
+std::atomic<int> g_group_m{0};       // "gemm_group_m": m-tiles per L2 tile group (0 = by shape, see auto_group_m)
 std::atomic<int> g_gemm_persist{1};  // "gemm_persist": persistent one-workgroup-per-CU launch of the 256x256 kernel
 std::atomic<int> g_gemm_streamk{1};  // "gemm_streamk": stream-K tail when the caller passes a workspace
 std::atomic<int> g_gemm_prefetch_r{0};   // "gemm_prefetch_residual": residual tile touched during the K loop (measured neutral: off)
@@ -1078,6 +1078,16 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
 
 }  // namespace
 
+// m-tiles per tile group of the XCD-contiguous order.  An XCD works on 32 neighbouring tiles at a time, gm m-tiles x 32 / gm n-tiles: gm + 32
+// / gm operand panels stream through its L2 (least at gm ~ 6).  Measured back to back at M = 65 792 (tools/gemm_group_sweep.py,
+// profiles/r02_group_sweep.txt): 6 is best where there are many n-tiles (QKV +1.6 %, fc1 +0.9 % over 4); with the six n-tiles of N = 1408 a
+// group of 3 is best at K = 1408 (proj +2.9 %) and a group of 2 at K = 6144, where one A panel alone is 3 MB (fc2 +1.1 %).
+static int auto_group_m(int N, int K) {
+    const int tn = (N + B2 - 1) / B2;
+    if (tn >= 8) return 6;
+    return K > 2048 ? 2 : 3;
+}
+
 extern "C" int seedmi_set_option(const char* key, int value) {
 #ifdef SEEDMI_DEVTOOLS
     const bool dev_variant = value == 232 || value == 255 || value == 257;
@@ -1088,7 +1098,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_group_m") && value >= 1 && value <= 64) {
+    if (key && !strcmp(key, "gemm_group_m") && value >= 0 && value <= 64) {
         g_group_m = value;
         return SEEDMI_OK;
     }
@@ -1191,7 +1201,7 @@ extern "C" int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda,
     p.C = (bf16_t*)C; p.ldc = ldc;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
-    p.group_m = g_group_m;
+    p.group_m = g_group_m > 0 ? (int)g_group_m : auto_group_m(N, K);
 #ifdef SEEDMI_DEVTOOLS
     const int abl = g_gemm_ablate;
     p.skip_epilogue = (abl == 32) ? 1 : (abl == 33 ? 2 : (abl == 34 ? 3 : (abl == 35 ? 4 : 0)));
