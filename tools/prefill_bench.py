@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seed_amd import config as C
 from seed_amd.llama_engine import LlamaEngine
 from seed_amd.weights import make_llama_state_dict
+from seed_amd import lib as L
+for kv in [x for x in os.environ.get("PREFILL_OPTS", "").split(",") if x]:      # e.g. PREFILL_OPTS="gemm_group_m=4"
+    k, v = kv.split("=")
+    L.check(L.load().seedmi_set_option(k.encode(), int(v)), kv)
 name = os.environ.get("MODEL", "14b")
 cfg = C.LLAMA_14B if name == "14b" else C.LLAMA_8B
 B, T = int(os.environ.get("B", "8")), 649
