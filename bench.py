@@ -204,11 +204,13 @@ def cpu_baseline(n_images):
 
 
 def _decode_traffic_ratio():
-    try:
-        d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_decode_gemm.json")))
-        return round(d["traffic_bytes"] / d["algorithmic_bytes"], 3)
-    except Exception:
-        return None
+    for name in ("r02_pmc_decode_gemm.json", "r01_pmc_decode_gemm.json"):
+        try:
+            d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)))
+            return round(d["traffic_bytes"] / d["algorithmic_bytes"], 3)
+        except Exception:
+            continue
+    return None
 
 
 def llama_decode_leg(B, n_new):
@@ -249,7 +251,7 @@ def llama_decode_leg(B, n_new):
             "ms_per_step": round(dt / steps * 1e3, 3), "prefill_ms": round(t_prefill * 1e3, 2), "prompt_len": T0,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_step": bytes_step,
-                         # PMC (profiles/r01_pmc_decode_gemm.json): the QKV weight-streaming launch moves 103.7 MB for 101.7 MB
+                         # PMC (profiles/r02_pmc_decode_gemm.json): the QKV weight-streaming launch moves 103.7 MB for 101.7 MB
                          "traffic_over_algorithmic_qkv_gemm": _decode_traffic_ratio()}}
 
 
