@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE — never imported by the product path (seed_amd/, models/).
 Only available in the build container (``/root/reference`` does not exist on the
-GPU box); used by ``oracle/make_golden.py`` and ``oracle/validate_restatement.py``
+GPU box); used by ``oracle/make_golden.py`` (golden vectors) and ``bench.py``'s reference CPU baseline
 to pin ``oracle/seed_oracle.py`` (the CPU restatement that *does* travel) against
 the reference's real code.
 
