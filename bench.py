@@ -200,6 +200,16 @@ def cpu_baseline(n_images):
                    "port_value": round(n_images / dt, 3)}
         except Exception as e:
             res["reference_error"] = repr(e)[:200]
+    else:
+        # the reference tree does not travel to the GPU box: next to the live port number, the reference's own modules as they were
+        # timed in the build container (a labelled constant with its core count and date, not a measurement of this run)
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_reference_baseline.json")))
+            res["reference_modules_build_container"] = {"kind": "reference", "value": d["value"], "unit": d["unit"], "cores": d["cores"],
+                                                        "measured": d["measured"], "date": d["date"], "sample": d["sample"],
+                                                        "source": "profiles/r03_cpu_reference_baseline.json (NOT measured in this run)"}
+        except Exception:
+            pass
     return res
 
 

@@ -38,7 +38,12 @@ extern "C" {
 #define SEEDMI_E_ARCH (-4)
 #define SEEDMI_E_HIP (-5)
 
-#define SEEDMI_ABI_VERSION 1
+/* Bumped whenever an existing entry point changes its argument list or a struct in this header changes layout (new entry points alone
+ * do not bump it).  1: round 1.  2: seedmi_sample_token_bf16 / seedmi_rope_kv_append / seedmi_llama_decode_attention_bf16 gained an
+ * argument before `stream`, seedmi_vit_layer_t grew by six pointers (LayerNorm fold).  3: seedmi_gemm_ext_t grew (tile-span statistics).
+ * A caller compiled against this header must check  seedmi_version() == SEEDMI_ABI_VERSION  before its first call: a mismatch
+ * means arguments and struct strides no longer line up (silent corruption, not an error).  seed_amd/lib.py does. */
+#define SEEDMI_ABI_VERSION 3
 
 int seedmi_version(void);
 const char* seedmi_last_error(void);
@@ -77,8 +82,12 @@ int seedmi_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* W,
 /* Same with a caller-owned workspace of seedmi_gemm_workspace_bytes() (256-byte aligned; its first 4 KiB must have been zeroed once,
  * e.g. by hipMemsetAsync ahead of the first call; may be reused by later calls on the SAME stream).  With it the persistent 256x256
  * kernel cuts its last, partial round of tiles along K into equal ranges (stream-K): every workgroup ends at the same time, and a
- * tile shared by two workgroups is summed in fp32 from one published partial - results equal the plain call up to that one
- * re-association of the fp32 sum.  workspace == NULL is exactly seedmi_gemm_bf16. */
+ * tile shared by two workgroups continues the fp32 accumulator image its partner published (the same k-ordered chain: results are
+ * bit-identical to the plain call).  The first 4 KiB are one flag word per workgroup; every flag is cleared again by the workgroup
+ * that consumed it, so the area is all-zero after each launch and the call may be captured in a hipGraph and replayed.  The LAST
+ * word (offset 4092) is a sticky error word: non-zero (1 + workgroup id) after a launch in which a workgroup gave up waiting for its
+ * partner's partial tile (bounded spin) - that tile of C is then wrong; clear the word to re-arm.  workspace == NULL is exactly
+ * seedmi_gemm_bf16. */
 size_t seedmi_gemm_workspace_bytes(void);
 /* LayerNorm folded into the two GEMMs around it (eva_vit.py:199-202: norm1 -> attn.qkv, norm2 -> mlp.fc1).
  * Consumer (BIAS / BIAS_GELU, N % 64 == 0, ln_stats != NULL): A holds the UN-normalised rows x, W holds half(weight * gamma); ln_stats

@@ -41,6 +41,7 @@ class ContinuousBatcher:
         self._ws_prefill = None
         self._graph = None
         self._slot_w = {}
+        self._generation = engine.cache_generation                               # of the cache addresses baked into _graph / _slot_w
         self.free = deque(range(self.B))
         self.waiting = deque()
         self.active: Dict[int, dict] = {}                                        # slot -> request state
@@ -58,7 +59,25 @@ class ContinuousBatcher:
             L.check(self.lib.seedmi_add_i32_vec(L.ptr(self.lens), L.ptr(self.inc), self.B, L.stream_ptr()), "seedmi_add_i32_vec")
             L.check(self.lib.seedmi_add_i32(L.ptr(self.step), 1, L.stream_ptr()), "seedmi_add_i32")
 
+    def _sync_generation(self):
+        """``LlamaEngine.resize_cache`` replaces the K/V cache tensors (a larger batch or context arrived elsewhere).  The captured
+        step and the per-slot weight structs hold raw addresses of the OLD tensors: drop them and rebuild on demand (the cached
+        positions were carried over, so requests in flight continue); refuse if the new cache no longer holds this batcher's slots."""
+        eng = self.eng
+        if eng.cache_generation == self._generation:
+            return
+        if self.B > eng.batch_cap:
+            raise L.SeedmiError(f"the KV cache was resized to {eng.batch_cap} rows but this batcher serves {self.B} slots")
+        for req in self.active.values():
+            if req["prompt"].numel() + req["max_new"] - 1 > eng.tmax:
+                raise L.SeedmiError("the KV cache was shrunk below the context of a request in flight")
+        self._graph, self._slot_w = None, {}
+        self._ws = torch.empty(self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), self.B, 1), dtype=torch.uint8, device=eng.device)
+        self._ws_prefill = None
+        self._generation = eng.cache_generation
+
     def _ensure_graph(self):
+        self._sync_generation()
         if self._graph is not None:
             return
         eng = self.eng
@@ -79,6 +98,7 @@ class ContinuousBatcher:
     # ------------------------------------------------------------------ slots
     def _slot_weights(self, s: int):
         """The engine's weight struct with every layer's cache pointers moved to row s: a batch-1 prefill through it fills slot s."""
+        self._sync_generation()
         if s not in self._slot_w:
             eng, cfg = self.eng, self.eng.cfg
             layers = (L.LlamaLayer * cfg.layers)()
@@ -107,6 +127,18 @@ class ContinuousBatcher:
         self._next_id += 1
         self.waiting.append({"id": rid, "prompt": p, "max_new": int(max_new_tokens)})
         return rid
+
+    def cancel(self, rid: int) -> bool:
+        """Remove a request that is still waiting (not yet prefilled into a slot)."""
+        for req in list(self.waiting):
+            if req["id"] == rid:
+                self.waiting.remove(req)
+                return True
+        return False
+
+    @property
+    def idle(self) -> bool:
+        return not self.waiting and not self.active
 
     def _admit(self):
         eng = self.eng
@@ -166,7 +198,7 @@ class ContinuousBatcher:
                         self._retire(s)
             if not self.active:
                 continue
-            self._ensure_graph()
+            self._ensure_graph()                                                 # (re-captured if the engine's cache was resized)
             self.step.zero_()
             if self.uniforms is not None:
                 self.uniforms.copy_(torch.rand(self.uniforms.shape, dtype=torch.float32, device=eng.device, generator=self.gen))

@@ -624,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 //    than two phases after its last read.
 // Raw s_barrier (not __syncthreads) so LDS-DMA stays in flight across barriers; waits are explicit.
 constexpr int B2 = 256;
+constexpr int SK_FLAGS_WORDS = 1024;               // stream-K flag area: one word per workgroup, the last one a sticky error word
 constexpr int MAX_SEGS = 512;                     // segment list of one workgroup in LDS (6 KiB)
 constexpr int SEG_BYTES = MAX_SEGS * 3 * 4;
 constexpr int SCRATCH_BYTES = 8 * 256;            // one 256-byte LDS-DMA landing row per wave (residual prefetch touches)
@@ -798,6 +799,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                    ++spins < (1 << 24))
                 __builtin_amdgcn_s_sleep(4);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // The flag is consumed: clear it, so that the flag area is all-zero again when the launch ends.  The epoch is a host
+            // counter frozen into the kernel arguments; a hipGraph REPLAY of this launch reuses it, and without the reset the
+            // previous replay's flag would already match (the wait skipped, a stale or half-written image read).  A partner that never
+            // showed up leaves a wrong tile: recorded in the sticky error word (last word of the flag area).
+            if (spins < (1 << 24)) __hip_atomic_store(p.sk_flags + partner, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(p.sk_flags + (SK_FLAGS_WORDS - 1), 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_slabs + (size_t)partner * (B2 * B2), 0,
@@ -1009,7 +1016,7 @@ int current_device() { return seedmi_current_device(); }
 int device_cus(int dev) { return seedmi_device_cus(dev); }
 
 constexpr size_t SK_SLAB_BYTES = (size_t)B2 * B2 * 4;       // one fp32 accumulator image per workgroup
-constexpr size_t SK_FLAGS_BYTES = 4096;                      // one flag word per workgroup (<= 1024 CUs)
+constexpr size_t SK_FLAGS_BYTES = 4 * SK_FLAGS_WORDS;        // one flag word per workgroup (< 1024 CUs) + the error word
 std::atomic<unsigned> g_sk_epoch{0};
 
 template <int EPI, bool LNF = false>
@@ -1029,7 +1036,7 @@ int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_b
     // stream-K tail: only a persistent launch whose every XCD holds at least one full round of tiles, and only when the last
     // round is partial (otherwise the data-parallel walk is already balanced and needs no exchange)
     p.sk_slabs = nullptr; p.sk_flags = nullptr; p.sk_epoch = 0;
-    if (sk_ws && g_gemm_streamk && grid == n_cu && nt >= grid && (nt % grid) != 0 && (grid % 8) == 0 && grid * 4 <= (int)SK_FLAGS_BYTES &&
+    if (sk_ws && g_gemm_streamk && grid == n_cu && nt >= grid && (nt % grid) != 0 && (grid % 8) == 0 && grid < SK_FLAGS_WORDS &&
         sk_ws_bytes >= SK_FLAGS_BYTES + (size_t)grid * SK_SLAB_BYTES) {
         p.sk_flags = (unsigned*)sk_ws;
         p.sk_slabs = (float*)((char*)sk_ws + SK_FLAGS_BYTES);

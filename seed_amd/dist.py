@@ -20,9 +20,11 @@ def shard_range(n_items: int, rank: int, world: int):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_token_ids(ids: torch.Tensor, dist=None, group=None) -> torch.Tensor:
-    """All-gather equal-sized [B_local, 32] id blocks into [world*B_local, 32] (rank order = shard order)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+def gather_token_ids(ids: torch.Tensor, dist=None, group=None, always_collective: bool = False) -> torch.Tensor:
+    """All-gather equal-sized [B_local, 32] id blocks into [world*B_local, 32] (rank order = shard order).
+    ``always_collective`` issues the collective at world size 1 too (the RCCL readiness test: a single-GPU box still goes through
+    ncclAllGather on the compute stream)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         return ids
     world = dist.get_world_size(group)
     out = torch.empty((world * ids.shape[0],) + tuple(ids.shape[1:]), dtype=ids.dtype, device=ids.device)

@@ -10,6 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEEDMI_LIB_PATH") or os.path.join(_HERE, "libseedmi.so")     # (override: A/B builds of the library)
 
+ABI_VERSION = 3            # == SEEDMI_ABI_VERSION of include/seedmi.h; load() refuses a library built from another header
+
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_BIAS_TANH, EPI_SWIGLU, EPI_PATCH_EMBED, EPI_RELU = range(8)
 
 _vp = C.c_void_p
@@ -140,6 +142,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    got = lib.seedmi_version()
+    if got != ABI_VERSION:
+        raise SeedmiError(f"{LIB_PATH} reports C-ABI version {got}, this binding was written for {ABI_VERSION} (include/seedmi.h): "
+                          "rebuild the library (`python -m seed_amd.build --force`); argument lists and struct layouts differ between versions")
     _lib = lib
     # tuning knobs for experiments: SEEDMI_OPTIONS="gemm_persist=0,gemm_group_m=4" (same keys as seedmi_set_option)
     for kv in filter(None, os.environ.get("SEEDMI_OPTIONS", "").split(",")):

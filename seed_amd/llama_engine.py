@@ -51,6 +51,7 @@ class LlamaEngine:
         self._ws = None
         self._ws_key = (0, 0)
         self.past_len = 0
+        self.cache_generation = 0              # bumped by resize_cache: consumers that baked cache addresses in compare it
         self._pack(state_dict)
 
     def _dev(self, t):
@@ -175,7 +176,8 @@ class LlamaEngine:
 
     def resize_cache(self, batch_cap: Optional[int] = None, tmax: Optional[int] = None):
         """Grow (or shrink) the static KV cache in place of a rebuild: the packed weights stay where they are, the cached
-        positions that fit are carried over.  Captured decode graphs of the old cache must not be replayed afterwards."""
+        positions that fit are carried over.  The cache tensors are REPLACED: everything that baked their addresses in (captured decode
+        graphs, ContinuousBatcher slot structs) is tied to ``cache_generation`` and refuses / rebuilds itself after a resize."""
         cfg = self.cfg
         nb, nt = batch_cap or self.batch_cap, tmax or self.tmax
         if (nb, nt) == (self.batch_cap, self.tmax):
@@ -191,6 +193,7 @@ class LlamaEngine:
         self.w.batch_cap, self.w.tmax = nb, nt
         self.past_len = min(self.past_len, nt)
         self._ws, self._ws_key = None, (0, 0)
+        self.cache_generation += 1
         return self
 
     # ------------------------------------------------------------------ hipGraph decode loop
@@ -264,8 +267,12 @@ class LlamaEngine:
             body()
         keep = (tok, counter, logits, ws, uniforms)          # buffers referenced by the graph
         left = [n_new - 1]                                   # steps the capture was sized for (cache rows, uniforms, out)
+        generation = self.cache_generation                   # the graph holds raw K/V cache addresses of THIS generation
 
         def replay(k: int):
+            if self.cache_generation != generation:
+                raise L.SeedmiError("replay(): the KV cache was resized (resize_cache) after this decode graph was captured; its kernels "
+                                    "would write the freed cache - capture a new graph")
             if k < 0 or k > left[0]:
                 raise L.SeedmiError(f"replay({k}): only {left[0]} of the {n_new - 1} captured decode steps remain "
                                     "(the graph writes the KV cache, `out` and reads `uniforms` by a device-side counter)")

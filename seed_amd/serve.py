@@ -20,6 +20,7 @@ FastAPI route when fastapi is installed (the reference uses Flask's dev server, 
 """
 import base64
 import io
+from collections import OrderedDict
 from typing import Callable, List, Optional
 
 import torch
@@ -60,7 +61,8 @@ class GenerateService:
         self.image_renderer = image_renderer        # embeds [1,D] -> PIL.Image (the diffusers pipeline, external)
         self.image_id_shift = IMAGE_ID_SHIFT
         self.device = device
-        self._batchers = {}                         # (top_p, temperature) -> ContinuousBatcher (the captured step bakes them in)
+        self._batchers = OrderedDict()              # (top_p, temperature) -> ContinuousBatcher (the captured step bakes them in), LRU
+        self.max_batchers = 4                       # each holds a logits buffer, a decode workspace and a captured hipGraph: bounded
         self.decode_chunk = 16
         self._batcher_factory = batcher_factory     # (top_p, temperature) -> object with submit(ids, max_new) / run() (tests)
 
@@ -69,13 +71,22 @@ class GenerateService:
             from .batching import ContinuousBatcher
         if temperature is None or temperature <= 0.0 or top_p is None or top_p <= 0.0:
             top_p, temperature = 0.0, 1.0             # degenerate sampling requests are greedy (temperature -> 0 limit)
-        key = (float(top_p), float(temperature))
-        if key not in self._batchers:
-            if self._batcher_factory is not None:
-                self._batchers[key] = self._batcher_factory(*key)
-            else:
-                self._batchers[key] = ContinuousBatcher(self.llm, chunk=self.decode_chunk, top_p=key[0], temperature=key[1],
-                                                        eos_token_id=self.tok.eos_token_id)
+        # client-supplied floats key device-side state: quantise them (1e-3 is far below any audible difference in sampling) and keep
+        # at most ``max_batchers`` configurations alive, evicting the least recently used IDLE one (its graph and buffers are freed)
+        key = (round(float(top_p), 3), round(float(temperature), 3))
+        if key in self._batchers:
+            self._batchers.move_to_end(key)
+            return self._batchers[key]
+        while len(self._batchers) >= self.max_batchers:
+            victim = next((k for k, cb in self._batchers.items() if getattr(cb, "idle", True)), None)
+            if victim is None:
+                break                               # every configuration is mid-request: exceed the cap rather than drop work
+            del self._batchers[victim]
+        if self._batcher_factory is not None:
+            self._batchers[key] = self._batcher_factory(*key)
+        else:
+            self._batchers[key] = ContinuousBatcher(self.llm, chunk=self.decode_chunk, top_p=key[0], temperature=key[1],
+                                                    eos_token_id=self.tok.eos_token_id)
         return self._batchers[key]
 
     # ---- seed_llama_flask.py:96-147: request fields, mixed raw / pre-tokenised images
@@ -130,19 +141,51 @@ class GenerateService:
                     max_new_tokens=max_new_tokens)
 
     def handle(self, request_info: dict) -> dict:
-        return self.handle_many([request_info])[0]
+        """One request, the Flask handler's contract: a malformed body fails the reference's own assert (seed_llama_flask.py:107)."""
+        return self.handle_many([request_info], raise_asserts=True)[0]
 
-    def handle_many(self, requests: List[dict]) -> List[dict]:
-        """Serve several /generate requests concurrently: requests with the same sampling configuration share one decode loop."""
-        parsed = [self._parse_request(r) for r in requests]
-        tickets = []
-        for q in parsed:
-            cb = self._batcher(q['top_p'], q['temperature'])
-            tickets.append((cb, cb.submit(q['input_ids'], q['max_new_tokens'])))
+    def handle_many(self, requests: List[dict], raise_asserts: bool = False) -> List[dict]:
+        """Serve several /generate requests concurrently: requests with the same sampling configuration share one decode loop.
+        A request that cannot be served (malformed, prompt beyond the context) gets an ``error_msg`` reply; its neighbours are served."""
+        # every request is parsed and checked BEFORE anything is queued: a bad request gets the reference-style error_msg reply and
+        # leaves nothing behind in a decode loop (a request queued before a later one raised would be decoded and discarded next call)
+        parsed, errors = [], {}
+        for i, r in enumerate(requests):
+            try:
+                q = self._parse_request(r)
+                tmax = getattr(self.llm, "tmax", None)
+                if tmax is not None and len(q['input_ids']) > tmax:
+                    raise ValueError(f"prompt of {len(q['input_ids'])} tokens exceeds the context of {tmax}")
+                if int(q['max_new_tokens']) < 1:
+                    raise ValueError("max_new_tokens must be at least 1")
+            except (AssertionError, ValueError, KeyError, TypeError) as e:
+                if raise_asserts and isinstance(e, AssertionError):
+                    raise
+                q = None
+                errors[i] = f'{type(e).__name__}: {e}' if str(e) else type(e).__name__
+            parsed.append(q)
+        tickets = {}
+        try:
+            for i, q in enumerate(parsed):
+                if q is not None:
+                    cb = self._batcher(q['top_p'], q['temperature'])
+                    tickets[i] = (cb, cb.submit(q['input_ids'], q['max_new_tokens']))
+        except Exception:
+            for cb, rid in tickets.values():          # nothing of a failed call stays queued
+                if hasattr(cb, "cancel"):
+                    cb.cancel(rid)
+            raise
         results = {}
-        for cb in {id(cb): cb for cb, _ in tickets}.values():
+        for cb in {id(cb): cb for cb, _ in tickets.values()}.values():
             results[id(cb)] = cb.run()
-        return [self._finish(q, torch.tensor(results[id(cb)][rid], dtype=torch.int64)) for q, (cb, rid) in zip(parsed, tickets)]
+        out = []
+        for i, q in enumerate(parsed):
+            if q is None:
+                out.append({'text': '', 'images': [], 'images_ids': [], 'error_msg': [errors[i]]})
+            else:
+                cb, rid = tickets[i]
+                out.append(self._finish(q, torch.tensor(results[id(cb)][rid], dtype=torch.int64)))
+        return out
 
     def _finish(self, q: dict, generate_ids: torch.Tensor) -> dict:
         images_ids_list = q['images_ids_list']

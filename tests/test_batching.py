@@ -73,3 +73,38 @@ def test_sampled_continuous_batching_is_reproducible_and_in_the_nucleus():
             order, k, _ = S.top_p_keep(lg[0, 0].float().cpu().numpy(), 1.0, 0.5)
             assert t in set(order[:k + 1].tolist())
             lg = eng.forward(torch.tensor([[t]], device="cuda"), last_only=True)
+
+
+def test_cache_resize_invalidates_baked_addresses():
+    """LlamaEngine.resize_cache REPLACES the K/V cache tensors.  A batcher that served requests before the resize (captured
+    step + per-slot weight structs hold the old addresses) must re-derive them - same tokens as before - and a decode graph captured
+    before the resize must refuse to replay instead of writing into the freed cache."""
+    from seed_amd import lib as L
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=9, norm_jitter=0.05)
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=3, tmax=64)
+    g = torch.Generator().manual_seed(5)
+    reqs = [(torch.randint(3, cfg.vocab, (T0,), generator=g), n) for T0, n in ((5, 9), (11, 14), (7, 6), (20, 12))]
+    want = [_alone(eng, p, n) for p, n in reqs]
+    cb = ContinuousBatcher(eng, slots=3, chunk=4)
+    ids = [cb.submit(p, n) for p, n in reqs[:2]]
+    out = cb.run()
+    assert [out[i] for i in ids] == want[:2]
+    gen0 = eng.cache_generation
+    first = eng.forward(reqs[0][0].view(1, -1).cuda(), last_only=True)[:, 0].float().argmax(-1, keepdim=True)
+    replay, _ = eng.capture_decode_graph(first, 4)
+    replay(1)
+    eng.resize_cache(batch_cap=5, tmax=96)                    # what LlamaForCausalLM does when a larger batch arrives
+    assert eng.cache_generation == gen0 + 1
+    junk = [torch.empty(3, cfg.heads, 64, cfg.head_dim, dtype=torch.bfloat16, device="cuda").fill_(float("nan")) for _ in range(8)]
+    with pytest.raises(L.SeedmiError, match="resized"):
+        replay(1)
+    ids = [cb.submit(p, n) for p, n in reqs]
+    out = cb.run()                                            # slot structs and the captured step are rebuilt for the new cache
+    assert [out[i] for i in ids] == want
+    assert cb._generation == eng.cache_generation
+    del junk
+    eng.resize_cache(batch_cap=2)                             # fewer rows than this batcher's slots: refused, not corrupted
+    cb.submit(*reqs[0])
+    with pytest.raises(L.SeedmiError, match="slots"):
+        cb.run()

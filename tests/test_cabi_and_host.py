@@ -25,7 +25,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True).stdout
     for name in declared:
         assert re.search(rf"\bT {name}\b", nm), f"{name} not exported"
-    assert l.seedmi_version() == 1
+    abi = int(re.search(r"#define\s+SEEDMI_ABI_VERSION\s+(\d+)", header).group(1))
+    assert l.seedmi_version() == abi == lib.ABI_VERSION          # header, library and binding agree (lib.load() refuses otherwise)
 
 
 def test_no_compute_without_gpu_is_loud():

@@ -197,6 +197,28 @@ def test_gemm_streamk_is_bit_identical_to_data_parallel(lib, M, N, K, epi, varia
         L.check(rc, "seedmi_gemm_bf16_ws")
         torch.cuda.synchronize()
         assert torch.equal(C0.view(torch.int16), C1.view(torch.int16)), f"stream-K result differs from data-parallel (rep {rep})"
+        # every flag was cleared by the workgroup that consumed it, and nobody gave up waiting (sticky error word = last word)
+        assert not ws[:4096].any(), "stream-K flag area is not all-zero after the launch"
+    # hipGraph replay: the epoch is frozen into the captured launch; replays rely on the consumed flags having been cleared
+    C2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+
+    def launch():
+        L.check(lib.seedmi_gemm_bf16_ws(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), 0 if res is None else N, code,
+                                        L.ptr(C2), N, 0, 0, L.ptr(ws), ws.numel(), L.stream_ptr()), "seedmi_gemm_bf16_ws")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launch()
+    for rep in range(3):
+        C2.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(C0.view(torch.int16), C2.view(torch.int16)), f"stream-K graph replay {rep} differs from data-parallel"
+        assert not ws[:4096].any()
     rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])          # fp32 check on the first / last tiles' rows
     acc = A[rows].float() @ W.float().t() + bias.float()
     want = {"bias": r(acc), "gelu": r(gelu(r(acc))), "residual": r(r(acc) + (res[rows].float() if res is not None else 0))}[epi]

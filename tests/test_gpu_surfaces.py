@@ -104,6 +104,51 @@ def test_scripts_tokenizer_construction_and_encode_image(tokenizer_dir):
     assert tokenizer.image_tokenizer.model._engine is before
 
 
+def test_reference_fixture_cat_jpg_both_preprocessing_routes(tokenizer_dir):
+    """scripts/seed_tokenizer_inference.py:12,20-29 on the reference's own fixture (tests/golden/cat.jpg = images/cat.jpg): the tokenizer
+    built by the scripts' hydra call, ``transform(image).to(device)`` -> ``encode_image(image_torch=...)``.  The PIL route
+    (models/transforms.py on the host) and the device route (``DevicePreprocessor``: decoded uint8 pixels uploaded, resize + normalise in
+    seedmi_preprocess_image_u8) must give EQUAL tensors and therefore equal ids, for the scripts' bilinear transform and for the bicubic
+    processor behind ``encode_image(image_path=...)`` / ``image_pil=`` (seed_llama_tokenizer.py:50-56,185-202)."""
+    from PIL import Image
+    from seed_amd.preprocess import DevicePreprocessor, BILINEAR, BICUBIC
+    d, sd, cfg = tokenizer_dir
+    assert cfg.img_size == 224
+    cat = os.path.join(ROOT, "tests", "golden", "cat.jpg")
+    tcfg = yaml.safe_load(open(os.path.join(ROOT, "configs/tokenizer/seed_llama_tokenizer_hf.yaml")))
+    xcfg = yaml.safe_load(open(os.path.join(ROOT, "configs/transform/clip_transform.yaml")))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tokenizer = _instantiate(tcfg, device="cuda", load_diffusion=True, pretrained_model_name_or_path=d,
+                                 encoder_url=os.path.join(d, "seed_quantizer.pt"), image_tokenizer_kwargs={"cfg": cfg})
+    transform = _instantiate(xcfg)
+    image = Image.open(cat).convert("RGB")                                                   # script line 26
+    image_tensor = transform(image).to("cuda")                                               # line 28
+    ids = tokenizer.encode_image(image_torch=image_tensor)                                   # line 29
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == (1, cfg.n_query) and 0 <= int(ids.min()) and int(ids.max()) < cfg.n_embed
+    dev = DevicePreprocessor(224, BILINEAR, keep_ratio=False)(image)
+    assert torch.equal(dev.cpu(), image_tensor.cpu()), "device preprocessing != models/transforms.py on cat.jpg"
+    assert torch.equal(tokenizer.encode_image(image_torch=dev), ids)
+    # the path / PIL branches run the bicubic processor (seed_llama_tokenizer.py:194-200)
+    by_path = tokenizer.encode_image(image_path=cat)
+    by_pil = tokenizer.encode_image(image_pil=image)
+    proc = tokenizer.image_tokenizer.processor(image)
+    by_torch = tokenizer.encode_image(image_torch=proc.to("cuda"))
+    assert torch.equal(by_path, by_pil) and torch.equal(by_path, by_torch)
+    dev3 = DevicePreprocessor(224, BICUBIC, keep_ratio=False)(image)
+    assert torch.equal(dev3.cpu(), proc)
+    assert torch.equal(tokenizer.encode_image(image_torch=dev3), by_path)
+    # and the ids are the oracle's on the engine's own z (VQ bit-exact), as for synthetic inputs
+    from seed_amd.tokenizer_engine import TokenizerEngine
+    taps = {}
+    eng = TokenizerEngine(sd, cfg, device="cuda")
+    assert torch.equal(eng.encode(image_tensor[None], taps), ids)
+    same_z = O.vq_argmin(taps["z"].float().cpu(), sd["quantize.embedding.weight"], O.Prec("bf16")).reshape(ids.shape)
+    assert torch.equal(ids.cpu(), same_z)
+    ids16 = O.get_codebook_indices(sd, image_tensor.cpu()[None], cfg, "bf16")
+    print(f"[cat.jpg] ids[:8] {ids[0, :8].tolist()}  agreement with the bf16 oracle {(ids.cpu() == ids16).float().mean().item():.3f}")
+
+
 @pytest.fixture(scope="module")
 def llama_dir(tmp_path_factory):
     from transformers.models.llama.configuration_llama import LlamaConfig as HF

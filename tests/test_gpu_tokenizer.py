@@ -229,3 +229,54 @@ def test_full_size_batch256_properties():
         assert torch.equal(eng.encode(img), ids)
     finally:
         lib.seedmi_set_option(b"tokenize_streams", 2)
+
+
+_RCCL_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["SEED_ROOT"])
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + os.environ["PORT"], rank=rank, world_size=world,
+                        device_id=torch.device("cuda", rank))
+from seed_amd import config as C
+from seed_amd.dist import tokenize_data_parallel, gather_token_ids
+from seed_amd.tokenizer_engine import TokenizerEngine
+from seed_amd.weights import make_tokenizer_state_dict
+cfg = C.TINY
+sd = make_tokenizer_state_dict(cfg, seed=0, ln_jitter=0.05)
+eng = TokenizerEngine(sd, cfg, device=f"cuda:{rank}")
+n = 5 * world + 2                                                   # ragged global batch
+images = torch.randn(n, 3, cfg.img_size, cfg.img_size, generator=torch.Generator().manual_seed(3)).cuda()
+whole = eng.encode(images)                                          # every rank: the single-process answer
+ids = tokenize_data_parallel(eng.encode, images, dist)              # shard, encode, RCCL all-gather of the int64 ids
+assert ids.dtype == torch.int64 and ids.shape == (n, cfg.n_query) and torch.equal(ids, whole), "DP ids differ from the single-process ids"
+blk = torch.full((256, 32), rank, dtype=torch.int64, device="cuda")  # config-4 block size: 64 KiB per rank
+out = gather_token_ids(blk, dist, always_collective=True)           # ncclAllGather even at world 1
+torch.cuda.synchronize()
+assert out.shape == (256 * world, 32) and all(bool((out[256 * r:256 * (r + 1)] == r).all()) for r in range(world))
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok", rank, world)
+"""
+
+
+def test_rccl_id_gather_on_every_visible_gpu(tmp_path):
+    """SURVEY 8e / BASELINE config 4 without an 8-GPU node: one process per visible GPU (1 on the test box), ``backend="nccl"`` (RCCL),
+    rendezvous on 127.0.0.1, the real TokenizerEngine under ``tokenize_data_parallel`` and the [256, 32] int64 all-gather that
+    bench.py issues at N > 1 - so the first multi-GPU run is not also the first RCCL run."""
+    import subprocess
+    import sys
+    world = torch.cuda.device_count()
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    port = str(31000 + os.getpid() % 2000)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PORT=port, SEED_ROOT=root,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rccl ok {r} {world}" in o, o[-3000:]

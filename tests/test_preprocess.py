@@ -4,6 +4,8 @@ The arithmetic belongs to Pillow / torchvision (not under /root/reference); the 
 numpy and is pinned here against the real Pillow (installed in the image, here and on the GPU box).  The HIP path
 (seedmi_preprocess_image_u8, through the C ABI) must be BIT-exact in its uint8 stage and produce identical fp32 values.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -55,6 +57,35 @@ def test_oracle_pipeline_matches_torch_pipeline(keep_ratio, filt):
     got, got_u8 = P.preprocess(img, 224, filt, keep_ratio)
     assert np.array_equal(got_u8, want_u8)
     assert np.array_equal(got, want.numpy())           # same fp32 operations in the same order
+
+
+
+CAT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cat.jpg")     # the reference's own fixture: images/cat.jpg
+
+
+def test_reference_fixture_cat_jpg_through_the_scripts_transform():
+    """scripts/seed_tokenizer_inference.py:12,22-28: ``images/cat.jpg`` -> ``Image.open(...).convert('RGB')`` ->
+    ``hydra.utils.instantiate(configs/transform/clip_transform.yaml)`` (= models.transforms.get_transform: Resize((224,224)) bilinear,
+    ToTensor, Normalize) -> tensor.  The reference records no expected ids for it, so the pin is: our
+    models/transforms.py and the ImageTokenizer.processor (bicubic, seed_llama_tokenizer.py:50-56) applied to the fixture EQUAL the
+    preprocessing oracle (itself bit-exact against Pillow, above) on the same decoded pixels."""
+    import yaml
+    from models.transforms import get_transform
+    from models.seed_llama_tokenizer import _make_processor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "transform", "clip_transform.yaml")))
+    assert cfg.pop("_target_") == "models.transforms.get_transform" and cfg == {"type": "clip", "image_size": 224, "keep_ratio": False}
+    image = Image.open(CAT).convert("RGB")
+    assert image.size == (690, 685)
+    px = np.asarray(image, dtype=np.uint8)
+    t = get_transform(**cfg)(image)
+    assert tuple(t.shape) == (3, 224, 224) and t.dtype == torch.float32
+    want, _ = P.preprocess(px, 224, 2, False)
+    assert np.array_equal(t.numpy(), want)
+    t3 = _make_processor(224)(image)                                                      # the image_path / image_pil branch
+    want3, _ = P.preprocess(px, 224, 3, False)
+    assert np.array_equal(t3.numpy(), want3)
+    assert not np.array_equal(want, want3)                                                # (the two routes really are different filters)
 
 
 @pytest.mark.gpu

@@ -125,6 +125,35 @@ def test_force_boi_counts_the_forced_token_as_generated_and_renderer_hook():
     assert img.size == (8, 8)
 
 
+def test_bad_requests_get_error_replies_and_leave_nothing_queued():
+    """every request is validated before any is queued - a prompt beyond the context or a malformed body in a batch of
+    requests yields a reference-style error_msg reply, the other requests are served, and no decode loop keeps a stale ticket."""
+    svc = _service([3 + ord('o'), 3 + ord('k'), 2])
+    svc.llm.tmax = 40
+    good = {'text': 'hi', 'images': []}
+    too_long = {'text': 'x' * 100, 'images': []}
+    malformed = {'text': 'no flag here', 'images': [list(range(32))]}
+    outs = svc.handle_many([good, too_long, malformed, good])
+    assert [o['text'] for o in outs] == ['ok', '', '', 'ok']
+    assert 'exceeds the context' in outs[1]['error_msg'][0] and outs[2]['error_msg'][0].startswith('AssertionError')
+    assert len(svc.llm.calls) == 2                                   # only the two good requests reached a decode loop
+    assert all(not b.q for b in svc._batchers.values())              # and nothing is left queued
+
+
+def test_sampling_configurations_are_bounded_lru():
+    """one decode loop (logits buffer + workspace + captured graph) per sampling configuration, keyed by client floats:
+    quantised, and at most ``max_batchers`` kept (least recently used idle one evicted)."""
+    svc = _service([2])
+    svc.max_batchers = 3
+    for k in range(10):
+        svc.handle({'text': 'q', 'images': [], 'temperature': 0.5 + 0.01 * k, 'top_p': 0.9})
+        assert len(svc._batchers) <= 3
+    a = svc._batcher(0.9, 0.70004)
+    assert svc._batcher(0.9, 0.70001) is a                            # quantised to 1e-3
+    svc._batcher(0.9, 0.1); svc._batcher(0.9, 0.2)
+    assert svc._batcher(0.9, 0.7) is a and len(svc._batchers) == 3    # recently used entries survive
+
+
 @pytest.mark.gpu
 def test_generate_end_to_end_on_device_engines():
     """Raw image -> device pre-processing -> tokenizer engine -> spliced prompt -> sampled graph decode -> parsed reply,
