@@ -50,6 +50,10 @@ std::atomic<int> g_gemm_streamk{1};  // "gemm_streamk": stream-K tail when the c
 std::atomic<int> g_gemm_prefetch_r{0};   // "gemm_prefetch_residual": residual tile touched during the K loop (measured neutral: off)
 std::atomic<int> g_gemm_residual_nt{1};  // "gemm_residual_nt": streaming stores for the BIAS_RESIDUAL output
 std::atomic<int> g_gemm_variant{0};  // "gemm": 0 = auto, 128 / 256 = force a kernel
+std::atomic<int> g_gemm_sched{0};    // "gemm_sched": schedule variant of the 256x256 kernel (bits: see gemm256_kernel), ViT epilogues only
+#ifdef SEEDMI_DEVTOOLS
+unsigned long long* g_gemm_dbg = nullptr;   // seedmi_gemm_phase_timing: device buffer for the phase clock stamps
+#endif
 std::atomic<int> g_gemm_min_tiles{160};   // "gemm_min_tiles": fewer 256x256 tiles than this -> 128x128 kernel
 
 struct GemmParams {
@@ -62,6 +66,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int group_m;                // m-tiles walked per group of the tile order (L2 locality)
 #ifdef SEEDMI_DEVTOOLS
+    unsigned long long* dbg;    // phase clock stamps of workgroup 0 (tools/gemm_phase_times.py), or null
     int skip_epilogue;          // timing ablations, seedmi_set_option("gemm_ablate", 32|33|34): 1 = no epilogue, 2 = epilogue without
                                 // its stores, 3 = ordinary instead of streaming stores, 4 = streaming stores without the lane transposition
 #else
@@ -88,6 +93,15 @@ struct GemmParams {
 
 SEEDMI_DEVINL int swzA(int row) { return (row >> 1) & 7; }
 SEEDMI_DEVINL int swzW(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+// lane id obtained where it is used (volatile: not hoisted).  Cold per-tile code of the 256x256 kernel (tile address set-up, fold operand
+// addresses, epilogue) derives its lane-dependent values from this instead of from threadIdx up front, so that they do not occupy
+// registers - or scratch slots, whose reloads are VM operations in the middle of the LDS-DMA pipeline - across the K loop.
+SEEDMI_DEVINL int fresh_lane() {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
 
 SEEDMI_DEVINL void glds16(const bf16_t* gptr, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
@@ -512,6 +526,81 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
     }
 }
 
+// BIAS / BIAS_GELU epilogue of the 256x256 kernel's LayerNorm-fold consumers (QKV, fc1) for the schedules that wait for the NEXT tile's
+// first K-tile inside the epilogue (SCHED bit 0): the accumulators are finished sums already (fold_accumulators ran), there is no
+// global load, N % 64 == 0 (no ragged span).  Same arithmetic as gemm_epilogue<EPI, 8, true, ., true>.  The first four rows are finished
+// and HELD (packed, 32 registers, while their 64 accumulators die) so that the next tile's LDS-DMA - issued right before the fold pass -
+// has the whole of that work to land in; then the hook waits for it (vmcnt retires in order: waiting AFTER the stores would also wait
+// for the stores, which is what the tile's opening wait used to do), and only then the tile's 16 stores go out.
+template <int EPI, typename Hook>
+SEEDMI_DEVINL void gemm_epilogue_fold8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li, const char* lut, Hook after_loads) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    if (nb >= p.N) {
+        after_loads();
+        return;
+    }
+    const uint32_t wcol = (uint32_t)((nb & ~63) + 8 * ((nb >> 4) & 3));
+    auto finish_row = [&](int mi, u32x4_t& oa, u32x4_t& oc) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk[i] = pack2bf(acc[mi][i >> 1][2 * (i & 1)], acc[mi][i >> 1][2 * (i & 1) + 1]);
+        if (EPI == EPI_BIAS_GELU) {                                   // GELU of the half fc1 output, by table (see gemm_epilogue)
+            bool bad = false;
+            uint32_t hw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                hw[i] = pk[i];
+                pk[i] = gelu_lut_pair(lut, hw[i], bad);
+            }
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) {              // wave-uniform, rare: |x| < 2^-16 or >= 16 somewhere
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t lo = hw[i] & 0xffffu, hi = hw[i] >> 16;
+                    const uint32_t fl = f2bf(gelu_erf(lo_bf(hw[i]))), fh = f2bf(gelu_erf(hi_bf(hw[i])));
+                    const uint32_t rl = gelu_in_table(lo) ? (pk[i] & 0xffffu) : fl;
+                    const uint32_t rh = gelu_in_table(hi) ? (pk[i] >> 16) : fh;
+                    pk[i] = rl | (rh << 16);
+                }
+            }
+        }
+        unsigned a[4] = {pk[0], pk[1], pk[2], pk[3]}, c[4] = {pk[4], pk[5], pk[6], pk[7]};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const auto t1 = __builtin_amdgcn_permlane16_swap(a[d], c[d], false, false);
+            const auto t2 = __builtin_amdgcn_permlane32_swap(t1[0], t1[1], false, false);
+            a[d] = t2[0];
+            c[d] = t2[1];
+        }
+        oa = (u32x4_t){a[0], a[1], a[2], a[3]};
+        oc = (u32x4_t){c[0], c[1], c[2], c[3]};
+    };
+    auto store_row = [&](int mi, const u32x4_t& oa, const u32x4_t& oc) {
+        const int m = mrow0 + 16 * mi + li;
+        if (m < p.M) {
+            bf16_t* wp = p.C + ((uint32_t)m * (uint32_t)p.ldc + wcol);
+            __builtin_nontemporal_store(oa, (u32x4_t*)wp);
+            __builtin_nontemporal_store(oc, (u32x4_t*)(wp + 32));
+        }
+    };
+    u32x4_t ha[4], hc[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        finish_row(mi, ha[mi], hc[mi]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    after_loads();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) store_row(mi, ha[mi], hc[mi]);
+#pragma unroll
+    for (int mi = 4; mi < 8; ++mi) {
+        u32x4_t oa, oc;
+        finish_row(mi, oa, oc);
+        store_row(mi, oa, oc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // XCD-contiguous, grouped (GROUP_M m-tiles x all n-tiles) workgroup -> tile map
 SEEDMI_DEVINL void tile_of_block(const GemmParams& p, int& tm, int& tn) {
     const int nt = p.tiles_m * p.tiles_n;
@@ -667,9 +756,19 @@ SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid
     return n_seg;
 }
 
-template <int EPI, bool LNF = false>
+// SCHED (seedmi_set_option("gemm_sched", ...)): variants of the schedule that compute bit-identical results.
+//   bit 0: the next tile's first K-tile is waited for INSIDE this tile's epilogue, after its loads and before its first store, and the tile's
+//          opening wait is dropped: vmcnt retires in order, so the opening wait (issued after the epilogue) also waited for 12 of the
+//          epilogue's 16 stores to reach memory.  LayerNorm-fold consumers take gemm_epilogue_fold8 (first four rows held back).
+//   bit 1: W(nh0) of K-tile kt+1 is read in P4 of K-tile kt (into the registers W(nh1) of kt just vacated; the two fragment sets swap
+//          roles every K-tile, so the loop is unrolled by two) instead of in P1 of kt+1: P1's LOAD section - 12 fragment reads + 4 LDS-DMA
+//          requests against 16 MFMAs of the partner wave - becomes 8 + 4, P4's 0 + 4 becomes 4 + 4.  Needs W(kt+1) retired one phase
+//          earlier: a counted vmcnt(4) in P3 (the four A(kt+1) requests of P1 stay in flight).
+//   bit 2: the A(kt+1) requests are split between P1 (half-tile 0) and P2 (half-tile 1) instead of all four in P1.
+template <int EPI, bool LNF = false, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr bool PRIO = SEEDMI_GEMM_PRIO;
+    constexpr bool PREWAIT = (SCHED & 1) != 0, WPRE = (SCHED & 2) != 0, ASPLIT = (SCHED & 4) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -727,12 +826,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         const int in_g = t - gid * gsize;
         m0 = (first_m + in_g % gm) * B2;
         n0 = (in_g / gm) * B2;
+        const int ln = SCHED != 0 ? fresh_lane() : lane;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int row = 128 * h + 16 * wave + 8 * j + (lane >> 3);     // row inside the 256-row tile
-                const int cs = lane & 7;
+                const int row = 128 * h + 16 * wave + 8 * j + (ln >> 3);       // row inside the 256-row tile
+                const int cs = ln & 7;
                 offA[h][j] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(row));
                 offW[h][j] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldw + 8u * (uint32_t)(cs ^ swzW(row));
             }
@@ -752,6 +852,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
+    };
+    auto stageA_half = [&](int kt, int h) {  // one A half-tile of K-tile kt (ASPLIT)
+        char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
     };
     auto stageW = [&](int kt) {
         char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
@@ -783,6 +889,193 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     issue_prologue(s_kb, s_ke);
 
     bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh) k0/k1 x 4 tiles ; W(nh0), W(nh1): k0/k1 x 2 tiles
+    bool pre_waited = false;                            // PREWAIT: the previous epilogue already waited for this segment's first K-tile
+#ifdef SEEDMI_DEVTOOLS
+    // phase clock stamps (tools/gemm_phase_times.py): waves 0 and 4 of workgroup 0 record s_memtime around every barrier of eight K-tiles of
+    // their second tile, plus the tile-level events, into LDS (no VM op, so the vmcnt pipeline is untouched); dumped at the kernel's end.
+    // s_memtime returns through the scalar cache (lgkmcnt): a stamp is only READ (stored) after one of the loop's own lgkmcnt(0) waits.
+    constexpr int DBG_OFF = STAT_OFF + (LNF ? 8 * 1024 : 0);
+    const bool dbg_wave = p.dbg != nullptr && blockIdx.x == 0 && (wave & 3) == 0;
+    char* const dbg_lds = smem + DBG_OFF + (wave >> 2) * 2048;
+    int dbg_n = 0, dbg_tile = 0;
+    unsigned long long dbg_t[4] = {0, 0, 0, 0};
+    int dbg_c[4] = {0, 0, 0, 0}, dbg_pending = 0;
+#define GSTAMP_ON (dbg_wave && dbg_tile == 1)
+#define GSTAMP(slot_, code_)                                                                   \
+    do {                                                                                       \
+        if (GSTAMP_ON) {                                                                       \
+            asm volatile("s_memtime %0" : "=s"(dbg_t[slot_]));                                 \
+            dbg_c[slot_] = (code_);                                                            \
+            dbg_pending = (slot_) + 1;                                                         \
+        }                                                                                      \
+    } while (0)
+    // after an lgkmcnt(0): the pending stamps have landed
+#define GSTAMP_FLUSH()                                                                         \
+    do {                                                                                       \
+        if (GSTAMP_ON) {                                                                       \
+            SEEDMI_SCHED_FENCE();                                                              \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                   \
+                if (q_ < dbg_pending && dbg_n < 250) {                                         \
+                    if (lane == 0) *(unsigned long long*)(dbg_lds + 8 * dbg_n) = (dbg_t[q_] & 0x00ffffffffffffffull) | ((unsigned long long)dbg_c[q_] << 56); \
+                    ++dbg_n;                                                                   \
+                }                                                                              \
+            dbg_pending = 0;                                                                   \
+            SEEDMI_SCHED_FENCE();                                                              \
+        }                                                                                      \
+    } while (0)
+#define GSTAMP_WAIT_FLUSH()                                                                    \
+    do {                                                                                       \
+        if (GSTAMP_ON) {                                                                       \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+            GSTAMP_FLUSH();                                                                    \
+        }                                                                                      \
+    } while (0)
+#else
+#define GSTAMP(slot_, code_) do {} while (0)
+#define GSTAMP_FLUSH() do {} while (0)
+#define GSTAMP_WAIT_FLUSH() do {} while (0)
+#endif
+
+    // ---- one K-tile, four phases.  fx holds / receives W(nh0), fy W(nh1).  WPRE: on entry fx already holds this K-tile's W(nh0) (read in the
+    //      previous K-tile's P4 or ahead of the loop); in P4 fy - dead after P3 - receives W(nh0) of K-tile kt + 1, so the caller swaps roles.
+    auto ktile = [&](const int kt, const int ke, bf16x8 (&fx)[4], bf16x8 (&fy)[4], const bool stamp) {
+        const char* sb = smem + (kt & 1) * KT_BYTES;
+        const char* pa0 = sb + rdA0;                    // k-step 0
+        const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
+        const char* pw0 = sb + rdW0;
+        const char* pw1 = sb + (rdW0 ^ 64);
+        (void)stamp;
+
+        // ================= P1: (mh0, nh0) =================
+        if (!WPRE) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { fx[t] = *(const bf16x8*)(pw0 + t * 512); fx[2 + t] = *(const bf16x8*)(pw1 + t * 512); }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
+        if (kt + 1 < ke) {
+            if (ASPLIT) stageA_half(kt + 1, 0);
+            else stageA(kt + 1);
+        }
+        if (EPI == EPI_BIAS_RESIDUAL && p.prefetch_residual) {
+            // The epilogue reads this tile's 128 KB of residual.  Left to the epilogue, all CUs ask HBM for their tiles in the same
+            // few microseconds (32 MB per round) while C goes the other way: measured +81 us on the proj GEMM, +68 us on fc2 (B = 256)
+            // over the bias-only epilogue.  Touch the wave's 128 x 128-byte residual block in four pieces spread over the last twelve
+            // K-tiles instead (one dword per 64-byte line by LDS-DMA into a scratch row: no VGPR destination, retired by this
+            // K-tile's own vmcnt(0) three phases later), so the lines wait in the Infinity Cache / L2 when the epilogue asks.
+            // (measured neutral to negative: off by default; not combined with the counted waits of SCHED bit 1)
+            const int rem = ke - 1 - kt;
+            if (!WPRE && (rem == 12 || rem == 9 || rem == 6 || rem == 3)) {
+                const int j = (12 - rem) / 3;
+                const int col = n0 + 64 * wn + 32 * (j & 1);
+                if (col < p.N) {
+                    const int row = min(m0 + 128 * wm + 64 * (j >> 1) + lane, p.M - 1);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.R + (size_t)row * p.ldr + col),
+                                                     (__attribute__((address_space(3))) void*)(smem + SCRATCH_OFF + wave * 256), 4, 0, 0);
+                }
+            }
+        }
+        SEEDMI_SCHED_FENCE();
+        if (stamp) GSTAMP(0, 10);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        if (stamp) { GSTAMP_FLUSH(); GSTAMP(0, 11); }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        if (stamp) GSTAMP(1, 12);
+        __builtin_amdgcn_s_barrier();
+        if (stamp) GSTAMP(2, 13);
+
+        // ================= P2: (mh0, nh1) =================
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { fy[t] = *(const bf16x8*)(pw0 + (2 + t) * 512); fy[2 + t] = *(const bf16x8*)(pw1 + (2 + t) * 512); }
+        if (ASPLIT && kt + 1 < ke) stageA_half(kt + 1, 1);
+        SEEDMI_SCHED_FENCE();
+        if (stamp) GSTAMP(3, 20);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        if (stamp) { GSTAMP_FLUSH(); GSTAMP(0, 21); }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        if (stamp) GSTAMP(1, 22);
+        __builtin_amdgcn_s_barrier();
+        if (stamp) GSTAMP(2, 23);
+
+        // ================= P3: (mh1, nh1) =================
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
+        // WPRE: W(kt+1) - requested in P4 of kt-1 (or by the prologue), i.e. older than the four A(kt+1) requests of this K-tile - must be
+        // complete one phase before P4 reads it
+        if (WPRE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        if (stamp) GSTAMP(3, 30);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        if (stamp) { GSTAMP_FLUSH(); GSTAMP(0, 31); }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        if (stamp) GSTAMP(1, 32);
+        __builtin_amdgcn_s_barrier();
+        if (stamp) GSTAMP(2, 33);
+
+        // ================= P4: (mh1, nh0) =================
+        // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 2 < ke) stageW(kt + 2);               // W slots of this parity were last read in P2
+        if (WPRE && kt + 1 < ke) {                     // next K-tile's W(nh0): other parity, retired by P3's counted wait + two barriers
+            const char* sn = smem + ((kt + 1) & 1) * KT_BYTES;
+            const char* qw0 = sn + rdW0;
+            const char* qw1 = sn + (rdW0 ^ 64);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { fy[t] = *(const bf16x8*)(qw0 + t * 512); fy[2 + t] = *(const bf16x8*)(qw1 + t * 512); }
+        }
+        SEEDMI_SCHED_FENCE();
+        if (stamp) GSTAMP(3, 40);
+        __builtin_amdgcn_s_barrier();
+        SEEDMI_SCHED_FENCE();
+        if (stamp) { GSTAMP_WAIT_FLUSH(); GSTAMP(0, 41); }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        SEEDMI_SCHED_FENCE();
+        if (stamp) GSTAMP(1, 42);
+        __builtin_amdgcn_s_barrier();
+        if (stamp) { GSTAMP(2, 43); GSTAMP_WAIT_FLUSH(); }
+    };
+
     for (;;) {
     const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
     const int fold_cur = fold_par ^ 1;                  // ... and its fold operand set
@@ -816,126 +1109,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (i * 4 + j) * 1024, 0));
+        pre_waited = false;                             // (the ordinary loads above are waited for by the compiler; keep the opening wait)
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // first K-tile complete (the up-to-4 youngest VM ops are the second W's LDS-DMA or the previous tile's epilogue stores)
-    if (ke - kb > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // first K-tile complete (the up-to-4 youngest VM ops are the second W's LDS-DMA or the previous tile's epilogue stores).
+    // PREWAIT: the previous tile's epilogue has waited for it already, ahead of its stores, which may still be on their way.
+    if (!(PREWAIT && pre_waited)) {
+        if (ke - kb > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    pre_waited = false;
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
     SEEDMI_SCHED_FENCE();
+#ifdef SEEDMI_DEVTOOLS
+    if (GSTAMP_ON) { GSTAMP(0, 1); GSTAMP_WAIT_FLUSH(); }
+#endif
 
     // A wave whose 64-column span lies beyond N (the half-empty last n-tile of N = 1408: the column groups wn = 2, 3) has nothing to
     // compute.  It walks the same barriers and issues its share of the LDS-DMA, but reads no fragments and issues no MFMA: the tile's
     // live waves keep the LDS bandwidth and the power budget to themselves (proj -2 %, fc2 -2.9 % at B = 256).
     const bool live = (en0 + 64 * wn) < p.N;
     if (live) {
-        for (int kt = kb; kt < ke; ++kt) {
-            const char* sb = smem + (kt & 1) * KT_BYTES;
-            const char* pa0 = sb + rdA0;                    // k-step 0
-            const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
-            const char* pw0 = sb + rdW0;
-            const char* pw1 = sb + (rdW0 ^ 64);
-
-            // ================= P1: (mh0, nh0) =================
+        if (WPRE) {
+            // W(nh0) of the segment's first K-tile (every later one is read in the P4 in front of it); the two fragment sets swap roles per K-tile
+            const char* sb = smem + (kb & 1) * KT_BYTES;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(pw0 + t * 512); fw0[2 + t] = *(const bf16x8*)(pw1 + t * 512); }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
-            if (kt + 1 < ke) stageA(kt + 1);
-            if (EPI == EPI_BIAS_RESIDUAL && p.prefetch_residual) {
-                // The epilogue reads this tile's 128 KB of residual.  Left to the epilogue, all CUs ask HBM for their tiles in the same
-                // few microseconds (32 MB per round) while C goes the other way: measured +81 us on the proj GEMM, +68 us on fc2 (B = 256)
-                // over the bias-only epilogue.  Touch the wave's 128 x 128-byte residual block in four pieces spread over the last twelve
-                // K-tiles instead (one dword per 64-byte line by LDS-DMA into a scratch row: no VGPR destination, retired by this
-                // K-tile's own vmcnt(0) three phases later), so the lines wait in the Infinity Cache / L2 when the epilogue asks.
-                const int rem = ke - 1 - kt;
-                if (rem == 12 || rem == 9 || rem == 6 || rem == 3) {
-                    const int j = (12 - rem) / 3;
-                    const int col = n0 + 64 * wn + 32 * (j & 1);
-                    if (col < p.N) {
-                        const int row = min(m0 + 128 * wm + 64 * (j >> 1) + lane, p.M - 1);
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.R + (size_t)row * p.ldr + col),
-                                                         (__attribute__((address_space(3))) void*)(smem + SCRATCH_OFF + wave * 256), 4, 0, 0);
-                    }
-                }
+            for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(sb + rdW0 + t * 512); fw0[2 + t] = *(const bf16x8*)(sb + (rdW0 ^ 64) + t * 512); }
+            int kt = kb;
+            for (; kt + 1 < ke; kt += 2) {
+                ktile(kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 12);
+                ktile(kt + 1, ke, fw1, fw0, kt - kb >= 4 && kt - kb < 12);
             }
-            SEEDMI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            SEEDMI_SCHED_FENCE();
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            SEEDMI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();
-
-            // ================= P2: (mh0, nh1) =================
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { fw1[t] = *(const bf16x8*)(pw0 + (2 + t) * 512); fw1[2 + t] = *(const bf16x8*)(pw1 + (2 + t) * 512); }
-            SEEDMI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            SEEDMI_SCHED_FENCE();
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            SEEDMI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();
-
-            // ================= P3: (mh1, nh1) =================
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
-            SEEDMI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            SEEDMI_SCHED_FENCE();
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            SEEDMI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();
-
-            // ================= P4: (mh1, nh0) =================
-            // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (kt + 2 < ke) stageW(kt + 2);               // W slots of this parity were last read in P2
-            SEEDMI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();
-            SEEDMI_SCHED_FENCE();
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            SEEDMI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();
+#if !defined(SEEDMI_EXP) || SEEDMI_EXP != 1
+            if (kt < ke) ktile(kt, ke, fw0, fw1, false);
+#endif
+        } else {
+            for (int kt = kb; kt < ke; ++kt) ktile(kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 12);
         }
     } else {
         for (int kt = kb; kt < ke; ++kt) {
@@ -952,13 +1166,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
     SEEDMI_SCHED_FENCE();
+#ifdef SEEDMI_DEVTOOLS
+    if (GSTAMP_ON) { GSTAMP(0, 90); }
+#endif
 
     if (FOLD_IN && ke == nk) {
         // LayerNorm fold, applied while nothing but the accumulators is live (ahead of the next tile's address set-up: placed inside
         // the epilogue it cost 110-290 B of scratch per lane, reloaded behind the tile's stores)
         FoldLds fold;
-        fold.cs = smem + STAT_OFF + fold_cur * 4096 + 4 * (64 * wn + 16 * g);
-        fold.st = smem + STAT_OFF + fold_cur * 4096 + 2048 + 8 * (128 * wm + li);
+        const int ln = SCHED != 0 ? fresh_lane() : lane;
+        fold.cs = smem + STAT_OFF + fold_cur * 4096 + 4 * (64 * wn + 16 * (ln >> 4));
+        fold.st = smem + STAT_OFF + fold_cur * 4096 + 2048 + 8 * (128 * wm + (ln & 15));
         fold_accumulators(acc, fold);
         SEEDMI_SCHED_FENCE();
     }
@@ -972,8 +1190,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             issue_prologue(s_kb, s_ke);
         }
     };
-    auto hook = [&]() { if (late) start_next(); };
+    // the epilogues call this once: after their own loads have landed, before their first store
+    auto hook = [&]() {
+        if (late) start_next();
+        if (PREWAIT && more) {
+            if (s_ke - s_kb > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (the second W's four requests stay in flight)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pre_waited = true;
+        }
+    };
     if (!late || ke < nk) start_next();
+#ifdef SEEDMI_DEVTOOLS
+    if (GSTAMP_ON) { GSTAMP(1, 91); }
+#endif
     if (ke < nk) {
         // ---- K head of a shared tile (the first stream-K segment): publish the accumulator image ([wave][4-register group][lane]
         //      x 16 B: every store instruction writes 1 KiB contiguous) write-through, then the flag.  Protocol of the CDNA guide
@@ -991,18 +1220,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __syncthreads();
         if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        const int enb = en0 + 64 * wn + 16 * g;
+        const int eln = SCHED != 0 ? fresh_lane() : lane;
+        const int eli = eln & 15;
+        const int enb = en0 + 64 * wn + 16 * (eln >> 4);
         if (EPI == EPI_BIAS_RESIDUAL && p.skip_epilogue == 0 && (enb & ~63) + 64 <= p.N) {
-            gemm_epilogue_residual8<LNF>(p, acc, em0 + 128 * wm, enb, li, hook, smem + STAT_OFF + wave * 1024);
+            gemm_epilogue_residual8<LNF>(p, acc, em0 + 128 * wm, enb, eli, hook, smem + STAT_OFF + wave * 1024);
+        } else if (PREWAIT && FOLD_IN && p.skip_epilogue == 0) {
+            gemm_epilogue_fold8<EPI>(p, acc, em0 + 128 * wm, enb, eli, lut, hook);
         } else if (p.skip_epilogue != 1) {
-            gemm_epilogue<EPI, 8, true, decltype(hook), LNF>(p, acc, em0 + 128 * wm, enb, li, lut, hook);
+            gemm_epilogue<EPI, 8, true, decltype(hook), LNF>(p, acc, em0 + 128 * wm, enb, eli, lut, hook);
         } else {
             hook();
             if (acc[0][0][0] == 123.456f) p.C[0] = 0;       // keep the accumulators alive
         }
     }
+#ifdef SEEDMI_DEVTOOLS
+    if (GSTAMP_ON) { GSTAMP(2, 93); GSTAMP_WAIT_FLUSH(); }
+    ++dbg_tile;
+#endif
     if (!more) break;
     }
+#ifdef SEEDMI_DEVTOOLS
+    if (dbg_wave) {                                     // dump: [2 stamped waves][256] x u64
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < 256; i += 64)
+            p.dbg[(wave >> 2) * 256 + i] = i < dbg_n ? *(const unsigned long long*)(dbg_lds + 8 * i) : 0ull;
+    }
+#endif
+#undef GSTAMP
+#undef GSTAMP_FLUSH
+#undef GSTAMP_WAIT_FLUSH
+#undef GSTAMP_ON
 }
 
 
@@ -1019,13 +1267,18 @@ constexpr size_t SK_SLAB_BYTES = (size_t)B2 * B2 * 4;       // one fp32 accumula
 constexpr size_t SK_FLAGS_BYTES = 4 * SK_FLAGS_WORDS;        // one flag word per workgroup (< 1024 CUs) + the error word
 std::atomic<unsigned> g_sk_epoch{0};
 
-template <int EPI, bool LNF = false>
-int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_bytes) {
+template <int EPI, bool LNF, int SCHED>
+int launch_gemm256_sched(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_bytes) {
+#ifdef SEEDMI_DEVTOOLS
+    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES + (LNF ? 8 * 1024 : 0) + 4096;     // + phase stamps
+    p.dbg = g_gemm_dbg;
+#else
     constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES + (LNF ? 8 * 1024 : 0);
+#endif
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, LNF, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set[dev] = true;
     }
     p.tiles_m = (p.M + B2 - 1) / B2;
@@ -1044,8 +1297,28 @@ int launch_gemm256(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_b
         if (e == 0) e = ++g_sk_epoch;                      // 0 is what a cleared flag area holds
         p.sk_epoch = e;
     }
-    hipLaunchKernelGGL((gemm256_kernel<EPI, LNF>), dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, LNF, SCHED>), dim3(grid), dim3(512), lds, stream, p);
     return seedmi_check_launch("gemm256");
+}
+
+// schedule variants (bit-identical results) exist for the three epilogues of the ViT GEMMs; everything else runs schedule 0
+template <int EPI, bool LNF = false>
+int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t sk_ws_bytes) {
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL) {
+        switch (g_gemm_sched.load()) {
+#ifdef SEEDMI_SCHED_ONLY                               // (register-pressure experiments: one variant, short compile)
+            case SEEDMI_SCHED_ONLY: return launch_gemm256_sched<EPI, LNF, SEEDMI_SCHED_ONLY>(p, stream, sk_ws, sk_ws_bytes);
+#else
+            case 1: return launch_gemm256_sched<EPI, LNF, 1>(p, stream, sk_ws, sk_ws_bytes);
+            case 2: return launch_gemm256_sched<EPI, LNF, 2>(p, stream, sk_ws, sk_ws_bytes);
+            case 3: return launch_gemm256_sched<EPI, LNF, 3>(p, stream, sk_ws, sk_ws_bytes);
+            case 6: return launch_gemm256_sched<EPI, LNF, 6>(p, stream, sk_ws, sk_ws_bytes);
+            case 7: return launch_gemm256_sched<EPI, LNF, 7>(p, stream, sk_ws, sk_ws_bytes);
+#endif
+            default: break;
+        }
+    }
+    return launch_gemm256_sched<EPI, LNF, 0>(p, stream, sk_ws, sk_ws_bytes);
 }
 
 #ifdef SEEDMI_DEVTOOLS
@@ -1105,6 +1378,10 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
+    if (key && !strcmp(key, "gemm_sched") && (value == 0 || value == 1 || value == 2 || value == 3 || value == 6 || value == 7)) {
+        g_gemm_sched = value;
+        return SEEDMI_OK;
+    }
     if (key && !strcmp(key, "gemm_group_m") && value >= 0 && value <= 64) {
         g_group_m = value;
         return SEEDMI_OK;
@@ -1145,6 +1422,12 @@ extern "C" int seedmi_set_option(const char* key, int value) {
     seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);
     return SEEDMI_E_SHAPE;
 }
+
+#ifdef SEEDMI_DEVTOOLS
+// devtools: device buffer of 2 x 256 uint64 that workgroup 0 of the next 256x256 GEMM launches fills with phase clock stamps
+// ((code << 56) | s_memtime; waves 0 and 4), or null to stop
+extern "C" int seedmi_gemm_phase_timing(void* buf) { g_gemm_dbg = (unsigned long long*)buf; return SEEDMI_OK; }
+#endif
 
 extern "C" size_t seedmi_gemm_workspace_bytes(void) {
     // stream-K tail of the persistent 256x256 kernel: a flag word and one fp32 accumulator image (256 KiB) per workgroup

@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""Interleaved A/B of the 256x256 GEMM's schedule variants (seedmi_set_option("gemm_sched", v)) on the four ViT shapes in the form the
+tokenizer issues them: QKV = BIAS + LayerNorm fold, fc1 = BIAS_GELU + fold, proj / fc2 = BIAS_RESIDUAL + row statistics.
+Every variant's output (and statistics) must be BIT-IDENTICAL to schedule 0's; timing = REPS back-to-back launches per round, ROUNDS rounds
+interleaved over the variants in one process (median and min ms, TFLOP/s of the median).
+
+    SCHEDS=0,1,2,3,6,7 SHAPES=qkv,proj,fc1,fc2 B=256 python tools/gemm_sched_ab.py
+"""
+import ctypes
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from seed_amd import lib as L  # noqa: E402
+
+lib = L.load()
+B = int(os.environ.get("B", "256"))
+REPS = int(os.environ.get("REPS", "40"))
+ROUNDS = int(os.environ.get("ROUNDS", "5"))
+SCHEDS = [int(v) for v in os.environ.get("SCHEDS", "0,1,2,3,6,7").split(",")]
+EXTRA = os.environ.get("EXTRA", "")          # further options applied to every arm, e.g. "gemm_group_m=4"
+ONLY = [x for x in os.environ.get("SHAPES", "").split(",") if x]
+OUT = os.environ.get("OUT", "gpurun_out/gemm_sched_ab.json")
+SHAPES = [("qkv", B * 257, 4224, 1408, L.EPI_BIAS), ("proj", B * 257, 1408, 1408, L.EPI_BIAS_RESIDUAL),
+          ("fc1", B * 257, 6144, 1408, L.EPI_BIAS_GELU), ("fc2", B * 257, 1408, 6144, L.EPI_BIAS_RESIDUAL)]
+for kv in filter(None, EXTRA.split(",")):
+    k, v = kv.split("=")
+    L.check(lib.seedmi_set_option(k.encode(), int(v)), kv)
+res = {}
+g = torch.Generator(device="cuda").manual_seed(0)
+for name, M, N, K, epi in SHAPES:
+    if ONLY and name not in ONLY:
+        continue
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.02).bfloat16()
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    if epi == L.EPI_BIAS_RESIDUAL:
+        bias = (torch.randn(N, device="cuda", generator=g) * 0.1).bfloat16()
+        R = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+        part = torch.empty(N // 64, M, 2, device="cuda")
+        ext = L.GemmExt(None, None, None, L.ptr(part), M)
+
+        def run():
+            L.check(lib.seedmi_gemm_bf16_ext(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(R), N, epi, L.ptr(C), N, 0, 0,
+                                             ctypes.byref(ext), None, 0, L.stream_ptr()), "gemm ext")
+        aux = part
+    else:
+        st = torch.rand(M + 1, 2, device="cuda", generator=g)
+        st[:, 1] += 0.5
+        cs, bf32 = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+        ext = L.GemmExt(L.ptr(st), L.ptr(cs), L.ptr(bf32), None, 0)
+
+        def run():
+            L.check(lib.seedmi_gemm_bf16_ext(M, N, K, L.ptr(A), K, L.ptr(W), K, None, None, 0, epi, L.ptr(C), N, 0, 0, ctypes.byref(ext),
+                                             None, 0, L.stream_ptr()), "gemm ext")
+        aux = None
+    ref_c, ref_aux, ok = None, None, {}
+    for v in SCHEDS:                                       # bit-identity first (C poisoned before every variant)
+        L.check(lib.seedmi_set_option(b"gemm_sched", v), "gemm_sched")
+        C.fill_(float("nan"))
+        if aux is not None:
+            aux.fill_(float("nan"))
+        run()
+        torch.cuda.synchronize()
+        if ref_c is None:
+            ref_c, ref_aux = C.clone(), None if aux is None else aux.clone()
+            ok[v] = True
+        else:
+            ok[v] = bool(torch.equal(C.view(torch.int16), ref_c.view(torch.int16))) and \
+                (aux is None or bool(torch.equal(aux.view(torch.int32), ref_aux.view(torch.int32))))
+            if not ok[v]:
+                bad = (C.view(torch.int16) != ref_c.view(torch.int16))
+                rows = bad.any(1).nonzero().flatten()
+                print(f"!! {name} sched {v}: {int(bad.sum())} elements differ, rows {rows[:8].tolist()} ... of {rows.numel()} rows; "
+                      f"cols {bad.any(0).nonzero().flatten()[:8].tolist()}", flush=True)
+    del ref_c, ref_aux
+    times = {v: [] for v in SCHEDS}
+    for r in range(ROUNDS + 1):
+        for v in SCHEDS:
+            lib.seedmi_set_option(b"gemm_sched", v)
+            run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(REPS):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            if r > 0:
+                times[v].append(e0.elapsed_time(e1) / REPS)
+    row = {}
+    for v in SCHEDS:
+        med, mn = statistics.median(times[v]), min(times[v])
+        row["sched_%d" % v] = {"median_ms": round(med, 4), "min_ms": round(mn, 4), "tflops": round(2.0 * M * N * K / med / 1e9, 1),
+                               "bit_identical_to_sched_0": ok[v]}
+    res[name] = row
+    print(name, json.dumps(row), flush=True)
+    del A, W, C
+lib.seedmi_set_option(b"gemm_sched", 0)
+os.makedirs(os.path.dirname(OUT) or ".", exist_ok=True)
+json.dump(res, open(OUT, "w"), indent=1)
