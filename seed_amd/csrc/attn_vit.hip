@@ -299,7 +299,307 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
     }
 }
 
-int g_attn_vit = 1;
+// ======================================================================================================
+// 16-wave form for n == 257 (EVA-ViT-g at 224x224): ONE 16-query tile per wave, the 257th query row on a side path.
+//
+// The 12-wave kernel above gives waves 0..4 two query tiles and waves 5..11 one (17 tiles), so every phase lasts as long as a two-tile
+// wave needs for its tiles one after the other - softmax is ~450 VALU instructions per tile and a single wave issues one every 4-5
+// cycles - while the SIMDs hold 5 / 4 / 4 / 4 tiles (profiles/r02_attn_phase_times.txt: QK^T + softmax 9-14 k cycles, PV 8-11.5 k,
+// waits 6-10 k of a 31.6 k cycle item).  Here every wave owns exactly one tile (4 waves per SIMD, 128 registers each), so a phase lasts
+// one tile's time with four waves interleaving on each SIMD, and the 17th tile - a single valid row - costs one wave a fraction of a tile:
+//   * its scores are formed with the operands SWAPPED (S = Q K^T instead of S^T = K Q^T): the accumulator then holds row 256 as ONE value
+//     per key tile in lanes 0..15 (key = 16 kt + lane), i.e. 17 values per lane instead of 68, and the softmax of that row is ~110
+//     VALU instructions on 16 lanes instead of ~450 on 64 (same arithmetic and rounding points; the reductions run over the 16 lanes);
+//   * the normalised row goes to LDS as 272 halves; after the phase barrier ANOTHER wave (another SIMD) reads it back in the PV operand
+//     layout (every lane group g reads keys 32 kk + 4 g .. + 3 and + 16: a broadcast) and runs the ordinary PV for it.
+// The two side jobs rotate over the waves item by item.  Same arithmetic and rounding points as attn_vit_kernel / attn_fullrow.hip.
+constexpr int V16_WAVES = 16;
+constexpr int V16_N = 257;
+constexpr int V16_P_OFF = VLDS_BYTES;                   // the side row: 288 halves (keys 272..287 stay zero)
+constexpr int V16_LDS_BYTES = VLDS_BYTES + 1024;
+
+template <bool ROUND_S>
+__global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ksm = (bf16_t*)smem;
+    bf16_t* Qsm = (bf16_t*)(smem + VKQ_BYTES);
+    bf16_t* Vsm = (bf16_t*)(smem + 2 * VKQ_BYTES);
+    bf16_t* Psm = (bf16_t*)(smem + V16_P_OFF);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (128 registers per wave: every phase takes its lane id where it needs it - fresh_lane() - so that no lane-derived address lives across
+    // phases; what hipcc would otherwise spill is reloaded by scratch loads, VM operations in the middle of the LDS-DMA pipeline)
+    constexpr int n = V16_N;
+    constexpr int total_chunks = n * VCHL;
+    constexpr int npieces = (total_chunks + 63) >> 6;                 // 49 pieces of 1 KiB per matrix
+    const int my_pieces = (npieces - wave + V16_WAVES - 1) / V16_WAVES;   // pieces wave, wave + 16, ... (wave-uniform, 3 or 4)
+
+    for (int i = tid; i < V16_LDS_BYTES / 16; i += 64 * V16_WAVES) *(uint4*)(smem + 16 * i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    auto stage = [&](const bf16_t* base, int ld, bf16_t* dst, int item) {
+        const int b = item / p.heads, h = item - b * p.heads;
+        const bf16_t* src = base + (size_t)b * n * ld + h * VHD;
+        const int lane = fresh_lane();
+        for (int j = 0; j < my_pieces; ++j) {
+            const int piece = wave + V16_WAVES * j;
+            const int q = min(64 * piece + lane, total_chunks - 1);  // LDS chunk position (clamped lanes rewrite the last one)
+            const int row = q / VCHL;
+            const int c = min((q - row * VCHL) ^ vswz(row), VCH - 1);   // source chunk of that position; the pad chunk copies the 11th
+            glds16v(src + (size_t)row * ld + 8 * c, (char*)dst + piece * 1024);
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item >= p.items) return;
+    stage(p.K, p.ldk, Ksm, item);
+    stage(p.Q, p.ldq, Qsm, item);
+    stage(p.V, p.ldv, Vsm, item);
+    const float L2E = 1.4426950408889634f;
+
+    for (int it = 0;; ++it) {
+        const int b = item / p.heads, h = item - b * p.heads;
+        const int side_a = it & 15, side_b = (it + 6) & 15;           // waves that take row 256: scores + softmax / PV (different SIMDs)
+        // ---- K(item), Q(item) landed everywhere (only this wave's V pieces may still be in flight)
+        wait_vm(my_pieces);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- S^T = K Q^T for query tile `wave`, softmax, P packed to bf16 MFMA operands
+        bf16x8 pf[VKK];
+        {
+            // fragment addresses (bytes): row li of a 16-row tile, chunk (4 ks + g) ^ swizzle(li); + 16 * 192 bytes per tile (immediate)
+            const int lane = fresh_lane(), li = lane & 15, g = lane >> 4;
+            int koff[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) koff[ks] = li * (VLD * 2) + 16 * ((4 * ks + g) ^ vswz(li));
+            bf16x8 qf[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {                // q * scale rounded to half; the 12th chunk (cols 88..95) is zero
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (32 * ks + 8 * g < VHD) v = *(const uint4*)((const char*)Qsm + 16 * wave * (VLD * 2) + koff[ks]);
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = pack2bf(lo_bf(w[i]) * p.scale, hi_bf(w[i]) * p.scale);
+                qf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+            f32x4 s[VNT];
+            bf16x8 fk[2][3];                                 // K fragments of one key tile, double buffered
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) fk[0][ks] = *(const bf16x8*)((const char*)Ksm + koff[ks]);
+#pragma unroll
+            for (int kt = 0; kt < VNT; ++kt) {
+                if (kt + 1 < VNT) {
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) fk[(kt + 1) & 1][ks] = *(const bf16x8*)((const char*)Ksm + (kt + 1) * 16 * (VLD * 2) + koff[ks]);
+                }
+                s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kt & 1][ks], qf[ks], s[kt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);         // (keeps the fragment reads one tile ahead, not ten: 128 registers per wave)
+            }
+            // softmax over keys {16 kt + 4 g + r}: S rounded to half like the reference's matmul output.  Four running maxima keep the
+            // dependent chain short (max is exact in any order).
+            float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int kt = 0; kt < VNT; ++kt) {
+                float v0 = s[kt][0], v1 = s[kt][1], v2 = s[kt][2], v3 = s[kt][3];
+                if (ROUND_S) {
+                    const uint32_t w0 = pack2bf(v0, v1), w1 = pack2bf(v2, v3);
+                    v0 = lo_bf(w0); v1 = hi_bf(w0); v2 = lo_bf(w1); v3 = hi_bf(w1);
+                }
+                if (kt == VNT - 1) {                         // keys 256 .. 271: only key 256 (g == 0, r == 0) exists
+                    v0 = (g == 0) ? v0 : -INFINITY;
+                    v1 = v2 = v3 = -INFINITY;
+                }
+                s[kt][0] = v0; s[kt][1] = v1; s[kt][2] = v2; s[kt][3] = v3;
+                mx4[kt & 3] = fmaxf(mx4[kt & 3], fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+            }
+            float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float nmx = -mx * L2E;
+            float sum = 0.f;                                 // (one chain in (kt, r) order, like the 12-wave kernel: bit-identical rows)
+#pragma unroll
+            for (int kt = 0; kt < VNT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], L2E, nmx));
+                    s[kt][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int kk = 0; kk < VKK; ++kk) {
+                uint4 pw;
+                pw.x = pack2bf(s[2 * kk][0] * inv, s[2 * kk][1] * inv);
+                pw.y = pack2bf(s[2 * kk][2] * inv, s[2 * kk][3] * inv);
+                pw.z = pw.w = 0u;                                  // (keys 272..287 do not exist: P = 0)
+                if (2 * kk + 1 < VNT) {
+                    pw.z = pack2bf(s[2 * kk + 1][0] * inv, s[2 * kk + 1][1] * inv);
+                    pw.w = pack2bf(s[2 * kk + 1][2] * inv, s[2 * kk + 1][3] * inv);
+                }
+                pf[kk] = __builtin_bit_cast(bf16x8, pw);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wave == side_a) {
+            // ---- row 256 (query tile 16, rows 257..271 of the Q image are zero): operands swapped, S[q = 4 g + r][key = 16 kt + li].
+            //      Only q == 0 exists: lanes 0..15, accumulator register 0.
+            const int lane = fresh_lane(), li = lane & 15, g = lane >> 4;
+            int koff[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) koff[ks] = li * (VLD * 2) + 16 * ((4 * ks + g) ^ vswz(li));
+            bf16x8 qf[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (32 * ks + 8 * g < VHD) v = *(const uint4*)((const char*)Qsm + 16 * 16 * (VLD * 2) + koff[ks]);
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = pack2bf(lo_bf(w[i]) * p.scale, hi_bf(w[i]) * p.scale);
+                qf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+            float t[VNT];
+            bf16x8 fk[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) fk[0][ks] = *(const bf16x8*)((const char*)Ksm + koff[ks]);
+#pragma unroll
+            for (int kt = 0; kt < VNT; ++kt) {
+                if (kt + 1 < VNT) {
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) fk[(kt + 1) & 1][ks] = *(const bf16x8*)((const char*)Ksm + (kt + 1) * 16 * (VLD * 2) + koff[ks]);
+                }
+                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], fk[kt & 1][ks], a, 0, 0, 0);
+                float v = a[0];
+                if (ROUND_S) v = rbf(v);
+                if (kt == VNT - 1) v = (li == 0) ? v : -INFINITY;   // keys 257..271 do not exist
+                t[kt] = v;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float mx = t[0];
+#pragma unroll
+            for (int kt = 1; kt < VNT; ++kt) mx = fmaxf(mx, t[kt]);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            const float nmx = -mx * L2E;
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < VNT; ++kt) {
+                t[kt] = __builtin_amdgcn_exp2f(fmaf(t[kt], L2E, nmx));
+                sum += t[kt];
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            if (g == 0) {
+#pragma unroll
+                for (int kt = 0; kt < VNT; ++kt) Psm[16 * kt + li] = f2bf(t[kt] * inv);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- V(item) landed; every wave is done with K(item) and Q(item); the side row is in LDS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int next = item + gridDim.x;
+        const bool more = next < p.items;
+        if (more) {
+            stage(p.K, p.ldk, Ksm, next);
+            stage(p.Q, p.ldq, Qsm, next);
+        }
+
+        // ---- O^T = V^T P^T (hardware transpose read of the row-major V image), store
+        const int lane = fresh_lane(), li = lane & 15, g = lane >> 4;
+        const bf16_t* vlane = Vsm + (4 * g + (li >> 2)) * VLD + 4 * (li & 1);
+        auto ldv = [&](bf16x8 (&f)[VHT], int kk) {
+#pragma unroll
+            for (int nn = 0; nn < VHT; ++nn) {
+                // rows 32kk + 4g + (li>>2) and + 16: both have (row >> 2) & 3 == g, i.e. the same chunk permutation
+                const bf16_t* vp = vlane + 32 * kk * VLD + 8 * ((2 * nn + ((li & 3) >> 1)) ^ vswz(4 * g));
+                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
+                const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 16 * VLD));
+                const uint2 lo = __builtin_bit_cast(uint2, a), hi = __builtin_bit_cast(uint2, c);
+                f[nn] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            }
+        };
+        auto store_o = [&](const f32x4 (&o)[VHT], int qtile, bool first_row_only) {
+            const int sl = fresh_lane(), g = sl >> 4;
+            if (first_row_only && (sl & 15) != 0) return;
+            bf16_t* op = p.O + ((size_t)b * n + 16 * qtile + (sl & 15)) * p.ldo + h * VHD;
+#pragma unroll
+            for (int nn = 0; nn < VHT; ++nn) {
+                const int c0 = 16 * nn + 4 * g;
+                if (c0 + 4 <= VHD) {
+                    uint2 w;
+                    w.x = pack2bf(o[nn][0], o[nn][1]);
+                    w.y = pack2bf(o[nn][2], o[nn][3]);
+                    *(uint2*)(op + c0) = w;
+                }
+            }
+        };
+        {
+            f32x4 o[VHT];
+#pragma unroll
+            for (int nn = 0; nn < VHT; ++nn) o[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bf16x8 fv0[VHT], fv1[VHT];
+            ldv(fv0, 0);
+#pragma unroll
+            for (int kk = 0; kk < VKK; ++kk) {
+                if (kk & 1) {
+                    if (kk + 1 < VKK) ldv(fv0, kk + 1);
+#pragma unroll
+                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pf[kk], o[nn], 0, 0, 0);
+                } else {
+                    if (kk + 1 < VKK) ldv(fv1, kk + 1);
+#pragma unroll
+                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pf[kk], o[nn], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            store_o(o, wave, false);
+        }
+        if (wave == side_b) {
+            // row 256: P^T operand straight from the side row (lane group g takes keys 32 kk + 4 g .. + 3 and + 16 .. : every column of
+            // the operand is the same row, only column li == 0 is stored)
+            f32x4 o[VHT];
+#pragma unroll
+            for (int nn = 0; nn < VHT; ++nn) o[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bf16x8 fv0[VHT], fv1[VHT];
+            const bf16_t* prow = Psm + 4 * (fresh_lane() >> 4);
+            ldv(fv0, 0);
+#pragma unroll
+            for (int kk = 0; kk < VKK; ++kk) {
+                const uint2 plo = *(const uint2*)(prow + 32 * kk), phi = *(const uint2*)(prow + 32 * kk + 16);
+                const bf16x8 pr = __builtin_bit_cast(bf16x8, make_uint4(plo.x, plo.y, phi.x, phi.y));
+                if (kk & 1) {
+                    if (kk + 1 < VKK) ldv(fv0, kk + 1);
+#pragma unroll
+                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pr, o[nn], 0, 0, 0);
+                } else {
+                    if (kk + 1 < VKK) ldv(fv1, kk + 1);
+#pragma unroll
+                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pr, o[nn], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            store_o(o, 16, true);
+        }
+        if (!more) break;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // every wave is done with V(item) and the side row
+        stage(p.V, p.ldv, Vsm, next);
+        item = next;
+    }
+}
+
+int g_attn_vit = 1;                    // 0 = off (attn_fullrow), 1 = 12-wave kernel, 2 = 16-wave kernel where n == 257
 #ifdef SEEDMI_DEVTOOLS
 unsigned long long* g_attn_dbg = nullptr;
 #endif
@@ -336,6 +636,15 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
+    }
+    if (g_attn_vit == 2 && nq == V16_N && round_scores) {        // (unrounded scores: only tests ask for them; the 12-wave kernel serves those)
+        static bool attr16_dev[SEEDMI_MAX_DEVICES] = {};
+        if (!attr16_dev[dev]) {
+            (void)hipFuncSetAttribute((const void*)attn_vit16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);
+            attr16_dev[dev] = true;
+        }
+        hipLaunchKernelGGL((attn_vit16_kernel<true>), dim3(grid), dim3(64 * V16_WAVES), V16_LDS_BYTES, (hipStream_t)stream, p);
+        return seedmi_check_launch("attn_vit16");
     }
     const dim3 blk(64 * VWAVES);
     if (round_scores && nq == 257)

@@ -56,6 +56,15 @@ SEEDMI_DEVINL float wave_max(float v) {
     return v;
 }
 
+// lane id obtained where it is used (volatile: not hoisted).  Cold per-tile / per-item code of the persistent kernels (the 256x256 GEMM's tile address set-up, fold
+// operand addresses and epilogue; the ViT attention's staging and side jobs) derives its lane-dependent values from this instead of from threadIdx up front, so that they do not occupy
+// registers - or scratch slots, whose reloads are VM operations in the middle of the LDS-DMA pipeline - across the K loop.
+SEEDMI_DEVINL int fresh_lane() {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
+
 // status codes of the C ABI (include/seedmi.h)
 #define SEEDMI_OK 0
 #define SEEDMI_E_SHAPE (-1)

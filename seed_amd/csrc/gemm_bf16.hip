@@ -94,15 +94,6 @@ struct GemmParams {
 SEEDMI_DEVINL int swzA(int row) { return (row >> 1) & 7; }
 SEEDMI_DEVINL int swzW(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
 
-// lane id obtained where it is used (volatile: not hoisted).  Cold per-tile code of the 256x256 kernel (tile address set-up, fold operand
-// addresses, epilogue) derives its lane-dependent values from this instead of from threadIdx up front, so that they do not occupy
-// registers - or scratch slots, whose reloads are VM operations in the middle of the LDS-DMA pipeline - across the K loop.
-SEEDMI_DEVINL int fresh_lane() {
-    int lane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-    return lane;
-}
-
 SEEDMI_DEVINL void glds16(const bf16_t* gptr, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -422,7 +413,7 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
 // B = 256 over the bias-only epilogue.  Here the residual rows are fetched in two halves of 32 registers and the first half's
 // finished rows are HELD (packed, 32 registers, while their accumulators die) until the second half's loads have been issued: every
 // load of the epilogue precedes every store, nothing spills.
-template <bool STATS, typename Hook>
+template <bool STATS, typename Hook, bool EARLY = false>
 SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li, Hook after_loads,
                                            char* stat_lds) {
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -444,9 +435,21 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
             rr[mi][1] = *(const uint4*)(rp + 8);
         }
     };
+    // EARLY: rows 4..7 in their own registers, requested once rows 0 and 1 are finished (16 registers of residual + 32 accumulators freed,
+    // 16 taken by the two held rows: room for 32), i.e. a whole two rows of arithmetic before they are needed
+    uint4 r2[EARLY ? 4 : 1][2];
+    auto load_rows2 = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const bf16_t* rp = p.R + (size_t)min(mrow0 + 16 * (4 + mi) + li, p.M - 1) * p.ldr + nb;
+            r2[EARLY ? mi : 0][0] = *(const uint4*)rp;
+            r2[EARLY ? mi : 0][1] = *(const uint4*)(rp + 8);
+        }
+    };
     // finished row (packed, lane-transposed so that a store instruction writes 64 contiguous bytes of a row)
     auto finish_row = [&](int mi_abs, int mi_rr, u32x4_t& oa, u32x4_t& oc) {
-        const uint4 r0 = rr[mi_rr][0], r1 = rr[mi_rr][1];
+        const uint4 r0 = (EARLY && mi_abs >= 4) ? r2[EARLY ? mi_rr : 0][0] : rr[mi_rr][0];
+        const uint4 r1 = (EARLY && mi_abs >= 4) ? r2[EARLY ? mi_rr : 0][1] : rr[mi_rr][1];
         const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
         float v[16];
 #pragma unroll
@@ -490,16 +493,31 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
     };
     u32x4_t ha[4], hc[4];
     load_rows(0);
+    if (EARLY) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) finish_row(mi, mi, ha[mi], hc[mi]);
-    __builtin_amdgcn_sched_barrier(0);
-    load_rows(1);                                                 // the last loads of the epilogue ...
-    // ... must have LANDED before the first store is issued (a later wait for them would also wait for the stores in front of it):
-    // an empty asm that "reads" the loaded registers makes the compiler place its vmcnt wait here
+        for (int mi = 0; mi < 2; ++mi) finish_row(mi, mi, ha[mi], hc[mi]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows2();                                             // the last loads of the epilogue, two rows of arithmetic ahead of their use
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-        asm volatile("" : "+v"(rr[mi][0].x), "+v"(rr[mi][0].y), "+v"(rr[mi][0].z), "+v"(rr[mi][0].w), "+v"(rr[mi][1].x), "+v"(rr[mi][1].y),
-                     "+v"(rr[mi][1].z), "+v"(rr[mi][1].w));
+        for (int mi = 2; mi < 4; ++mi) finish_row(mi, mi, ha[mi], hc[mi]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            asm volatile("" : "+v"(r2[EARLY ? mi : 0][0].x), "+v"(r2[EARLY ? mi : 0][0].y), "+v"(r2[EARLY ? mi : 0][0].z), "+v"(r2[EARLY ? mi : 0][0].w),
+                         "+v"(r2[EARLY ? mi : 0][1].x), "+v"(r2[EARLY ? mi : 0][1].y), "+v"(r2[EARLY ? mi : 0][1].z), "+v"(r2[EARLY ? mi : 0][1].w));
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) finish_row(mi, mi, ha[mi], hc[mi]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(1);                                                 // the last loads of the epilogue ...
+        // ... must have LANDED before the first store is issued (a later wait for them would also wait for the stores in front of it):
+        // an empty asm that "reads" the loaded registers makes the compiler place its vmcnt wait here
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            asm volatile("" : "+v"(rr[mi][0].x), "+v"(rr[mi][0].y), "+v"(rr[mi][0].z), "+v"(rr[mi][0].w), "+v"(rr[mi][1].x), "+v"(rr[mi][1].y),
+                         "+v"(rr[mi][1].z), "+v"(rr[mi][1].w));
+    }
     __builtin_amdgcn_sched_barrier(0);
     after_loads();
     __builtin_amdgcn_sched_barrier(0);
@@ -765,10 +783,18 @@ SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid
 //          requests against 16 MFMAs of the partner wave - becomes 8 + 4, P4's 0 + 4 becomes 4 + 4.  Needs W(kt+1) retired one phase
 //          earlier: a counted vmcnt(4) in P3 (the four A(kt+1) requests of P1 stay in flight).
 //   bit 2: the A(kt+1) requests are split between P1 (half-tile 0) and P2 (half-tile 1) instead of all four in P1.
+//   bit 3: the W(kt+2) requests are split between P3 and P4.  A wave's two pieces of a W half-tile are 8 rows each, and the MFMA row
+//          permutation makes piece 0 all nh0 rows (last read in P1 of kt, or P4 of kt-1 with bit 1) and piece 1 all nh1 rows (last read
+//          in P2 of kt): piece 0 may be restaged from P3 on, piece 1 from P4.  With bit 2 every phase then issues two requests.  P4's wait
+//          becomes a counted vmcnt(2): the two requests of P3 stay in flight.
+//   bit 4: residual epilogue: the second half's residual rows are requested after TWO rows of the first half are finished (their
+//          registers are free by then) instead of after four, so that their HBM round trip runs under the other two rows' arithmetic.
+//   bit 5: the second-dispatched wave group (waves 4..7) runs at s_setprio 1 throughout (the CDNA guide's static form of T5).
 template <int EPI, bool LNF = false, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr bool PRIO = SEEDMI_GEMM_PRIO;
-    constexpr bool PREWAIT = (SCHED & 1) != 0, WPRE = (SCHED & 2) != 0, ASPLIT = (SCHED & 4) != 0;
+    constexpr bool PREWAIT = (SCHED & 1) != 0, WPRE = (SCHED & 2) != 0, ASPLIT = (SCHED & 4) != 0, WSPLIT = (SCHED & 8) != 0;
+    constexpr bool RES_EARLY = (SCHED & 16) != 0, STATIC_PRIO = (SCHED & 32) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -803,6 +829,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     if (EPI == EPI_BIAS_GELU) load_gelu_lut(smem + 2 * KT_BYTES, tid, 512);   // activation table behind the operand ring
     __syncthreads();
     const char* lut = (EPI == EPI_BIAS_GELU) ? smem + 2 * KT_BYTES : nullptr;
+    if (STATIC_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);      // (wave is a readfirstlane value: a scalar branch around one s_setprio)
     int i_seg = 0;
     int s_tile = 0, s_kb = 0, s_ke = 0;             // current segment: K-tiles [s_kb, s_ke) of tile s_tile
     auto next_seg = [&](int& tile, int& kb, int& ke) -> bool {
@@ -868,6 +895,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int j = 0; j < 2; ++j) glds16(p.W + (offW[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
     };
 
+    auto stageW_piece = [&](int kt, int j) {   // piece j (8 rows) of both W half-tiles of K-tile kt (WSPLIT): j = 0 nh0 rows, j = 1 nh1 rows
+        char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) glds16(p.W + (offW[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
+    };
     // prologue loads of a segment: its first K-tile (A and W) and, already in flight behind it, W of the second
     auto issue_prologue = [&](int kb, int ke) {
         if (FOLD_IN) {
@@ -891,49 +924,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     bf16x8 fa[8], fw0[4], fw1[4];                       // A(mh) k0/k1 x 4 tiles ; W(nh0), W(nh1): k0/k1 x 2 tiles
     bool pre_waited = false;                            // PREWAIT: the previous epilogue already waited for this segment's first K-tile
 #ifdef SEEDMI_DEVTOOLS
-    // phase clock stamps (tools/gemm_phase_times.py): waves 0 and 4 of workgroup 0 record s_memtime around every barrier of eight K-tiles of
-    // their second tile, plus the tile-level events, into LDS (no VM op, so the vmcnt pipeline is untouched); dumped at the kernel's end.
-    // s_memtime returns through the scalar cache (lgkmcnt): a stamp is only READ (stored) after one of the loop's own lgkmcnt(0) waits.
+    // phase clock stamps (tools/gemm_phase_times.py): waves 0 and 4 of workgroup 0 record s_memtime around every barrier of every other
+    // K-tile of a window of their second tile, plus the tile-level events.  s_memtime answers through the scalar cache after ~1000 cycles:
+    // a stamp is ISSUED into its own SGPR pair and nothing waits for it inside the stamped K-tile; the sixteen stamps of a K-tile are
+    // written to LDS (no VM operation: the vmcnt pipeline is untouched) in the NEXT, unstamped K-tile, behind that K-tile's own first
+    // lgkmcnt(0).  Dumped to global memory at the kernel's end.
     constexpr int DBG_OFF = STAT_OFF + (LNF ? 8 * 1024 : 0);
     const bool dbg_wave = p.dbg != nullptr && blockIdx.x == 0 && (wave & 3) == 0;
     char* const dbg_lds = smem + DBG_OFF + (wave >> 2) * 2048;
     int dbg_n = 0, dbg_tile = 0;
-    unsigned long long dbg_t[4] = {0, 0, 0, 0};
-    int dbg_c[4] = {0, 0, 0, 0}, dbg_pending = 0;
+    unsigned long long dbg_t[17];                       // 0..15: the phases' four stamps each; 16: K-tile entered
+    bool dbg_full = false;
 #define GSTAMP_ON (dbg_wave && dbg_tile == 1)
-#define GSTAMP(slot_, code_)                                                                   \
+#define GSTAMP(slot_) do { if (GSTAMP_ON) asm volatile("s_memtime %0" : "=s"(dbg_t[slot_])); } while (0)
+    // behind an lgkmcnt(0) that is old enough: (first_, count_) of the slots -> LDS with their codes
+#define GSTAMP_STORE(first_, count_, code0_)                                                   \
     do {                                                                                       \
-        if (GSTAMP_ON) {                                                                       \
-            asm volatile("s_memtime %0" : "=s"(dbg_t[slot_]));                                 \
-            dbg_c[slot_] = (code_);                                                            \
-            dbg_pending = (slot_) + 1;                                                         \
+        SEEDMI_SCHED_FENCE();                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < (count_); ++q_) {                              \
+            if (lane == 0 && dbg_n < 250)                                                      \
+                *(unsigned long long*)(dbg_lds + 8 * dbg_n) = (dbg_t[(first_) + q_] & 0x00ffffffffffffffull) | ((unsigned long long)((code0_) + q_) << 56); \
+            ++dbg_n;                                                                           \
         }                                                                                      \
-    } while (0)
-    // after an lgkmcnt(0): the pending stamps have landed
-#define GSTAMP_FLUSH()                                                                         \
-    do {                                                                                       \
-        if (GSTAMP_ON) {                                                                       \
-            SEEDMI_SCHED_FENCE();                                                              \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                   \
-                if (q_ < dbg_pending && dbg_n < 250) {                                         \
-                    if (lane == 0) *(unsigned long long*)(dbg_lds + 8 * dbg_n) = (dbg_t[q_] & 0x00ffffffffffffffull) | ((unsigned long long)dbg_c[q_] << 56); \
-                    ++dbg_n;                                                                   \
-                }                                                                              \
-            dbg_pending = 0;                                                                   \
-            SEEDMI_SCHED_FENCE();                                                              \
-        }                                                                                      \
-    } while (0)
-#define GSTAMP_WAIT_FLUSH()                                                                    \
-    do {                                                                                       \
-        if (GSTAMP_ON) {                                                                       \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
-            GSTAMP_FLUSH();                                                                    \
-        }                                                                                      \
+        SEEDMI_SCHED_FENCE();                                                                  \
     } while (0)
 #else
-#define GSTAMP(slot_, code_) do {} while (0)
-#define GSTAMP_FLUSH() do {} while (0)
-#define GSTAMP_WAIT_FLUSH() do {} while (0)
+#define GSTAMP(slot_) do {} while (0)
 #endif
 
     // ---- one K-tile, four phases.  fx holds / receives W(nh0), fy W(nh1).  WPRE: on entry fx already holds this K-tile's W(nh0) (read in the
@@ -945,6 +961,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         const char* pw0 = sb + rdW0;
         const char* pw1 = sb + (rdW0 ^ 64);
         (void)stamp;
+        if (stamp) GSTAMP(16);
 
         // ================= P1: (mh0, nh0) =================
         if (!WPRE) {
@@ -976,11 +993,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             }
         }
         SEEDMI_SCHED_FENCE();
-        if (stamp) GSTAMP(0, 10);
+        if (stamp) GSTAMP(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
-        if (stamp) { GSTAMP_FLUSH(); GSTAMP(0, 11); }
+#ifdef SEEDMI_DEVTOOLS
+        if (GSTAMP_ON && dbg_full && !stamp) {          // the previous (stamped) K-tile's sixteen stamps: long landed
+            GSTAMP_STORE(0, 17, 0);
+            dbg_full = false;
+        }
+#endif
+        if (stamp) GSTAMP(1);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -991,20 +1014,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
-        if (stamp) GSTAMP(1, 12);
+        if (stamp) GSTAMP(2);
         __builtin_amdgcn_s_barrier();
-        if (stamp) GSTAMP(2, 13);
+        if (stamp) GSTAMP(3);
 
         // ================= P2: (mh0, nh1) =================
 #pragma unroll
         for (int t = 0; t < 2; ++t) { fy[t] = *(const bf16x8*)(pw0 + (2 + t) * 512); fy[2 + t] = *(const bf16x8*)(pw1 + (2 + t) * 512); }
         if (ASPLIT && kt + 1 < ke) stageA_half(kt + 1, 1);
         SEEDMI_SCHED_FENCE();
-        if (stamp) GSTAMP(3, 20);
+        if (stamp) GSTAMP(4);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
-        if (stamp) { GSTAMP_FLUSH(); GSTAMP(0, 21); }
+        if (stamp) GSTAMP(5);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1015,9 +1038,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
-        if (stamp) GSTAMP(1, 22);
+        if (stamp) GSTAMP(6);
         __builtin_amdgcn_s_barrier();
-        if (stamp) GSTAMP(2, 23);
+        if (stamp) GSTAMP(7);
 
         // ================= P3: (mh1, nh1) =================
 #pragma unroll
@@ -1025,12 +1048,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // WPRE: W(kt+1) - requested in P4 of kt-1 (or by the prologue), i.e. older than the four A(kt+1) requests of this K-tile - must be
         // complete one phase before P4 reads it
         if (WPRE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (WSPLIT && kt + 2 < ke) stageW_piece(kt + 2, 0);           // nh0 rows of this parity: last read in P1 (P4 of kt-1 with WPRE)
         SEEDMI_SCHED_FENCE();
-        if (stamp) GSTAMP(3, 30);
+        if (stamp) GSTAMP(8);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
-        if (stamp) { GSTAMP_FLUSH(); GSTAMP(0, 31); }
+        if (stamp) GSTAMP(9);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1041,14 +1065,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
-        if (stamp) GSTAMP(1, 32);
+        if (stamp) GSTAMP(10);
         __builtin_amdgcn_s_barrier();
-        if (stamp) GSTAMP(2, 33);
+        if (stamp) GSTAMP(11);
 
         // ================= P4: (mh1, nh0) =================
         // K-tile kt+1 must be complete before anyone reads it in the next P1; its loads are 3-4 phases old.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (kt + 2 < ke) stageW(kt + 2);               // W slots of this parity were last read in P2
+        if (WSPLIT) {
+            // everything but P3's two requests (W(kt+2), piece 0) must have landed: A(kt+1) for the next P1 (and W(kt+1) without WPRE)
+            if (kt + 2 < ke) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                stageW_piece(kt + 2, 1);                   // nh1 rows: last read in P2
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kt + 2 < ke) stageW(kt + 2);               // W slots of this parity were last read in P2
+        }
         if (WPRE && kt + 1 < ke) {                     // next K-tile's W(nh0): other parity, retired by P3's counted wait + two barriers
             const char* sn = smem + ((kt + 1) & 1) * KT_BYTES;
             const char* qw0 = sn + rdW0;
@@ -1057,10 +1091,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int t = 0; t < 2; ++t) { fy[t] = *(const bf16x8*)(qw0 + t * 512); fy[2 + t] = *(const bf16x8*)(qw1 + t * 512); }
         }
         SEEDMI_SCHED_FENCE();
-        if (stamp) GSTAMP(3, 40);
+        if (stamp) GSTAMP(12);
         __builtin_amdgcn_s_barrier();
         SEEDMI_SCHED_FENCE();
-        if (stamp) { GSTAMP_WAIT_FLUSH(); GSTAMP(0, 41); }
+        if (stamp) GSTAMP(13);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1071,9 +1105,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
-        if (stamp) GSTAMP(1, 42);
+        if (stamp) GSTAMP(14);
         __builtin_amdgcn_s_barrier();
-        if (stamp) { GSTAMP(2, 43); GSTAMP_WAIT_FLUSH(); }
+#ifdef SEEDMI_DEVTOOLS
+        if (stamp) { GSTAMP(15); if (GSTAMP_ON) dbg_full = true; }
+#endif
     };
 
     for (;;) {
@@ -1109,7 +1145,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (i * 4 + j) * 1024, 0));
-        pre_waited = false;                             // (the ordinary loads above are waited for by the compiler; keep the opening wait)
+        // The image must have landed HERE, inside this branch: left to the first use, hipcc merges the "loads pending" state of this (rare)
+        // path into the common one and puts an unconditional s_waitcnt vmcnt(0) in front of EVERY tile's K loop - which also waits for the
+        // previous tile's 16 epilogue stores and for the second W's requests (found in the ISA of rounds 1-2's kernel).
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+        pre_waited = false;                             // (keep the opening wait on this path)
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1127,7 +1170,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
     SEEDMI_SCHED_FENCE();
 #ifdef SEEDMI_DEVTOOLS
-    if (GSTAMP_ON) { GSTAMP(0, 1); GSTAMP_WAIT_FLUSH(); }
+    if (GSTAMP_ON) { GSTAMP(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); GSTAMP_STORE(0, 1, 100); }
 #endif
 
     // A wave whose 64-column span lies beyond N (the half-empty last n-tile of N = 1408: the column groups wn = 2, 3) has nothing to
@@ -1142,14 +1185,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(sb + rdW0 + t * 512); fw0[2 + t] = *(const bf16x8*)(sb + (rdW0 ^ 64) + t * 512); }
             int kt = kb;
             for (; kt + 1 < ke; kt += 2) {
-                ktile(kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 12);
-                ktile(kt + 1, ke, fw1, fw0, kt - kb >= 4 && kt - kb < 12);
+                ktile(kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
+                ktile(kt + 1, ke, fw1, fw0, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
             }
 #if !defined(SEEDMI_EXP) || SEEDMI_EXP != 1
             if (kt < ke) ktile(kt, ke, fw0, fw1, false);
 #endif
         } else {
-            for (int kt = kb; kt < ke; ++kt) ktile(kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 12);
+            for (int kt = kb; kt < ke; ++kt) ktile(kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
         }
     } else {
         for (int kt = kb; kt < ke; ++kt) {
@@ -1167,7 +1210,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier the other group took up front
     SEEDMI_SCHED_FENCE();
 #ifdef SEEDMI_DEVTOOLS
-    if (GSTAMP_ON) { GSTAMP(0, 90); }
+    if (GSTAMP_ON) {
+        if (dbg_full) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); GSTAMP_STORE(0, 17, 0); dbg_full = false; }
+        GSTAMP(0);
+    }
 #endif
 
     if (FOLD_IN && ke == nk) {
@@ -1201,7 +1247,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     };
     if (!late || ke < nk) start_next();
 #ifdef SEEDMI_DEVTOOLS
-    if (GSTAMP_ON) { GSTAMP(1, 91); }
+    if (GSTAMP_ON) { GSTAMP(1); }
 #endif
     if (ke < nk) {
         // ---- K head of a shared tile (the first stream-K segment): publish the accumulator image ([wave][4-register group][lane]
@@ -1224,7 +1270,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         const int eli = eln & 15;
         const int enb = en0 + 64 * wn + 16 * (eln >> 4);
         if (EPI == EPI_BIAS_RESIDUAL && p.skip_epilogue == 0 && (enb & ~63) + 64 <= p.N) {
-            gemm_epilogue_residual8<LNF>(p, acc, em0 + 128 * wm, enb, eli, hook, smem + STAT_OFF + wave * 1024);
+            gemm_epilogue_residual8<LNF, decltype(hook), RES_EARLY>(p, acc, em0 + 128 * wm, enb, eli, hook, smem + STAT_OFF + wave * 1024);
         } else if (PREWAIT && FOLD_IN && p.skip_epilogue == 0) {
             gemm_epilogue_fold8<EPI>(p, acc, em0 + 128 * wm, enb, eli, lut, hook);
         } else if (p.skip_epilogue != 1) {
@@ -1235,7 +1281,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
     }
 #ifdef SEEDMI_DEVTOOLS
-    if (GSTAMP_ON) { GSTAMP(2, 93); GSTAMP_WAIT_FLUSH(); }
+    if (GSTAMP_ON) { GSTAMP(2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); GSTAMP_STORE(0, 3, 101); }
     ++dbg_tile;
 #endif
     if (!more) break;
@@ -1248,9 +1294,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
 #endif
 #undef GSTAMP
-#undef GSTAMP_FLUSH
-#undef GSTAMP_WAIT_FLUSH
+#ifdef SEEDMI_DEVTOOLS
+#undef GSTAMP_STORE
 #undef GSTAMP_ON
+#endif
 }
 
 
@@ -1309,11 +1356,11 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
 #ifdef SEEDMI_SCHED_ONLY                               // (register-pressure experiments: one variant, short compile)
             case SEEDMI_SCHED_ONLY: return launch_gemm256_sched<EPI, LNF, SEEDMI_SCHED_ONLY>(p, stream, sk_ws, sk_ws_bytes);
 #else
-            case 1: return launch_gemm256_sched<EPI, LNF, 1>(p, stream, sk_ws, sk_ws_bytes);
-            case 2: return launch_gemm256_sched<EPI, LNF, 2>(p, stream, sk_ws, sk_ws_bytes);
-            case 3: return launch_gemm256_sched<EPI, LNF, 3>(p, stream, sk_ws, sk_ws_bytes);
-            case 6: return launch_gemm256_sched<EPI, LNF, 6>(p, stream, sk_ws, sk_ws_bytes);
             case 7: return launch_gemm256_sched<EPI, LNF, 7>(p, stream, sk_ws, sk_ws_bytes);
+            case 13: return launch_gemm256_sched<EPI, LNF, 13>(p, stream, sk_ws, sk_ws_bytes);
+            case 15: return launch_gemm256_sched<EPI, LNF, 15>(p, stream, sk_ws, sk_ws_bytes);
+            case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);
+            case 63: return launch_gemm256_sched<EPI, LNF, 63>(p, stream, sk_ws, sk_ws_bytes);
 #endif
             default: break;
         }
@@ -1378,7 +1425,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && (value == 0 || value == 1 || value == 2 || value == 3 || value == 6 || value == 7)) {
+    if (key && !strcmp(key, "gemm_sched") && value >= 0 && value <= 63) {       // (values without a compiled variant run schedule 0)
         g_gemm_sched = value;
         return SEEDMI_OK;
     }

@@ -248,19 +248,33 @@ def test_llama8b_full_depth_config3_parity():
         assert (d16 <= tol).all(), (tag, d16.max().item(), tol.min().item())
         report["steps"][tag] = {"rel_vs_fp32": _rel(kept[i], r32), "rel_bf16_oracle_vs_fp32": _rel(r16, r32), "rel_vs_bf16_oracle": _rel(kept[i], r16),
                                 "max_abs_vs_bf16_oracle": d16.max().item(), "max_abs_logit": r32.abs().max().item()}
-    # greedy ids: the engine's token after context i vs the fp32 oracle's argmax at the same context, on confident rows
-    s32 = l32[:, T0 - 1:T0 + n_steps]                                                       # [B, 129, V]
+    # greedy ids: the engine's token after context i vs the fp32 oracle's argmax at the same context.  SURVEY 8d's margin (top-2 gap >
+    # 1e-2 * max|logit|) was chosen for shallow stacks: after 32 layers two bf16 pipelines differ from fp32 by more than that (the bf16
+    # ORACLE's own argmax flips on such rows, counted below), so a row is "confident" when its fp32 top-2 gap exceeds 3x the bf16 oracle's
+    # own largest logit deviation on that row - a pipeline within 1.5x the oracle's deviation (asserted above at the probes) cannot flip it.
+    s32, s16 = l32[:, T0 - 1:T0 + n_steps], l16[:, T0 - 1:T0 + n_steps]                     # [B, 129, V]
     top2 = s32.topk(2, dim=-1).values
-    confident = (top2[..., 0] - top2[..., 1]) > 1e-2 * s32.abs().amax(-1)
+    gap = top2[..., 0] - top2[..., 1]
+    dev16 = (s16 - s32).abs().amax(-1)
+    confident = gap > 3.0 * dev16
+    loose = gap > 1e-2 * s32.abs().amax(-1)
     same = graphed.cpu() == s32.argmax(-1)
-    assert (same | ~confident).all(), f"{(~same & confident).sum().item()} greedy ids differ from the fp32 oracle on confident rows"
+    same16 = s16.argmax(-1) == s32.argmax(-1)
     report["greedy_agreement"] = same.float().mean().item()
+    report["greedy_agreement_bf16_oracle"] = same16.float().mean().item()
     report["confident_fraction"] = confident.float().mean().item()
-    print(f"[8B full depth] greedy agreement {report['greedy_agreement']:.3f} over {same.numel()} positions, confident "
-          f"{report['confident_fraction']:.3f}; oracle {oracle_s:.1f} s")
+    report["survey_margin_rows"] = {"fraction": loose.float().mean().item(), "hip_differs": int((~same & loose).sum()),
+                                    "bf16_oracle_differs": int((~same16 & loose).sum())}
+    print(f"[8B full depth] greedy agreement with the fp32 oracle: hip {report['greedy_agreement']:.3f} / bf16 oracle "
+          f"{report['greedy_agreement_bf16_oracle']:.3f} over {same.numel()} positions; confident {report['confident_fraction']:.3f}; "
+          f"rows above the 1e-2 margin: hip differs on {report['survey_margin_rows']['hip_differs']}, the bf16 oracle itself on "
+          f"{report['survey_margin_rows']['bf16_oracle_differs']}; oracle {oracle_s:.1f} s")
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(report, open(os.path.join(out, "llama8b_depth_parity.json"), "w"), indent=1)
+    assert (same | ~confident).all(), f"{(~same & confident).sum().item()} greedy ids differ from the fp32 oracle on confident rows"
+    # and the HIP path is no worse at picking the fp32 oracle's token than the oracle's own bf16 choreography (3 flips of slack)
+    assert (~same).sum() <= (~same16).sum() * 1.25 + 3, ((~same).sum().item(), (~same16).sum().item())
     del sd_cpu, l32, l16
     gc.collect()
 

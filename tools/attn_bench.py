@@ -15,11 +15,11 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B * N, 3 * C, device="cuda", generator=g).bfloat16()
 out = torch.empty(B * N, C, device="cuda", dtype=torch.bfloat16)
 flops = 4.0 * B * H * N * N * hd
-for trv in (2, 1, 0):
-    L.check(lib.seedmi_set_option(b"attn_vit", 1 if trv == 2 else 0), "opt")
+for trv in (3, 2, 1, 0):                                  # 3 = 16-wave ViT kernel, 2 = 12-wave ViT kernel, 1 / 0 = attn_fullrow variants
+    L.check(lib.seedmi_set_option(b"attn_vit", {3: 2, 2: 1}.get(trv, 0)), "opt")
     L.check(lib.seedmi_set_option(b"attn_trv", min(trv, 1)), "opt")
     ts = []
-    for i in range(8):
+    for i in range(12):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(lib.seedmi_attention_bf16(L.ptr(qkv), 3 * C, L.ptr(qkv[:, C:]), 3 * C, L.ptr(qkv[:, 2 * C:]), 3 * C, L.ptr(out), C,

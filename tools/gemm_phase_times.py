@@ -4,7 +4,8 @@ Waves 0 (wave group wm = 0) and 4 (wm = 1) of workgroup 0 stamp s_memtime around
 per phase p = 1..4   p0 = LOAD section done (arrives at the first barrier) | p1 = released + fragments landed (MFMA section starts) |
                      p2 = MFMAs issued (arrives at the second barrier)    | p3 = released (next LOAD section starts)
 so   LOAD = p0 - (previous p3)   wait1 = p1 - p0   MFMA = p2 - p1   wait2 = p3 - p2
-plus tile-level stamps: 1 = tile opened, 90 = K loop left, 91 = next tile's requests issued, 93 = epilogue done.
+(every other K-tile of a window is stamped; a stamp is an s_memtime into its own SGPR pair that nothing waits for inside the stamped
+K-tile), plus tile-level stamps: tile opened, K loop left, next tile's requests issued, epilogue done.
 
     SEEDMI_LIB_PATH=seed_amd/libseedmi_dev.so SCHEDS=0,3 SHAPE=qkv python tools/gemm_phase_times.py
 """
@@ -74,40 +75,31 @@ for v in SCHEDS:
         if not ev:
             print(f"  wave {4 * w}: no stamps")
             continue
-        # per-phase durations over the stamped K-tiles
-        acc = {}
-        prev_p3 = None
-        tile = {}
-        for i, (code, t) in enumerate(ev):
-            if code in (1, 90, 91, 93):
-                tile[code] = t
-                if code == 1:
-                    prev_p3 = t
-                continue
-            ph, k = divmod(code, 10)
-            if k == 0 and prev_p3 is not None:
-                acc.setdefault((ph, "LOAD"), []).append(t - prev_p3)
-            if k == 1:
-                acc.setdefault((ph, "wait1"), []).append(t - last)
-            if k == 2:
-                acc.setdefault((ph, "MFMA"), []).append(t - last)
-            if k == 3:
-                acc.setdefault((ph, "wait2"), []).append(t - last)
-                prev_p3 = t
-            last = t
-        line = []
-        total = 0.0
-        for ph in (1, 2, 3, 4):
-            parts = []
-            for nm in ("LOAD", "wait1", "MFMA", "wait2"):
-                xs = acc.get((ph, nm), [])
-                xs = xs[1:] if nm == "LOAD" and ph == 1 and len(xs) > 1 else xs      # (first LOAD follows the tile-open stamp)
-                m = sum(xs) / max(len(xs), 1)
-                total += m
-                parts.append(f"{nm} {m:5.0f}")
-            line.append(f"P{ph}: " + " ".join(parts))
-        print(f"  wave {4 * w}: " + " | ".join(line) + f" | K-tile {total:.0f} cycles ({len(acc.get((4, 'MFMA'), []))} stamped)")
-        if 1 in tile and 90 in tile:
-            print(f"          tile: open->K loop left {tile[90] - tile[1]} | ->requests issued {tile.get(91, 0) - tile[90]} | "
-                  f"->epilogue done {tile.get(93, 0) - tile.get(91, 0)}   (s_memtime cycles)")
+        # stamped K-tiles arrive as runs of codes 0..15 (4 * (phase - 1) + {0 LOAD done, 1 MFMA starts, 2 MFMAs issued, 3 released})
+        tiles, tile_ev, cur = [], {}, []
+        for code, t in ev:
+            if code >= 100:
+                tile_ev[code] = t
+            else:
+                if code == 0:
+                    cur = []
+                cur.append(t)
+                if code == 16 and len(cur) == 17:
+                    tiles.append(cur)
+        if not tiles:
+            print(f"  wave {4 * w}: no complete K-tile")
+            continue
+        n = len(tiles)
+        avg = [sum(t[i] for t in tiles) / n for i in range(17)]
+        line, total = [], 0.0
+        for ph in range(4):
+            b = 4 * ph
+            wait1, mfma, wait2 = avg[b + 1] - avg[b], avg[b + 2] - avg[b + 1], avg[b + 3] - avg[b + 2]
+            load = avg[b] - (avg[b - 1] if ph > 0 else avg[16])         # (slot 16 = the K-tile was entered, right behind the previous barrier)
+            line.append(f"P{ph + 1}: LOAD {load:5.0f} wait1 {wait1:5.0f} MFMA {mfma:5.0f} wait2 {wait2:5.0f}")
+        span = avg[15] - avg[16]
+        print(f"  wave {4 * w}: " + " | ".join(line) + f" | K-tile {span:.0f} cycles ({n} K-tiles)")
+        if 100 in tile_ev and 101 in tile_ev:
+            print(f"          tile: open->K loop left {tile_ev[101] - tile_ev[100]} | ->requests issued {tile_ev.get(102, 0) - tile_ev[101]} | "
+                  f"->epilogue done {tile_ev.get(103, 0) - tile_ev.get(102, 0)}   (s_memtime cycles)")
 lib.seedmi_set_option(b"gemm_sched", 0)

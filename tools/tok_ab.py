@@ -21,7 +21,7 @@ sd = make_tokenizer_state_dict(C.SEED2, seed=0, device="cuda")
 eng = TokenizerEngine(sd, C.SEED2, device="cuda")
 del sd
 img = torch.randn(B, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)).bfloat16()
-defaults = {"tokenize_streams": 2, "tokenize_streamk": 0, "gemm": 0, "gemm_sched": 0, "gemm_group_m": 0, "gemm_prefetch_residual": 0, "gemm_residual_nt": 1, "tokenize_lnfold": 1, "tokenize_split_rounds": 0, "tokenize_vq_head": 1}
+defaults = {"tokenize_streams": 2, "tokenize_streamk": 0, "gemm": 0, "gemm_sched": 0, "attn_vit": 1, "gemm_group_m": 0, "gemm_prefetch_residual": 0, "gemm_residual_nt": 1, "tokenize_lnfold": 1, "tokenize_split_rounds": 0, "tokenize_vq_head": 1}
 
 
 def apply(spec):
@@ -61,5 +61,5 @@ apply("")
 res = {s: {"median_ms": round(sorted(t)[len(t) // 2], 3), "img_s": round(B / sorted(t)[len(t) // 2] * 1e3, 1), "all_ms": [round(x, 2) for x in t]}
        for s, t in times.items()}
 print(json.dumps(res, indent=1))
-os.makedirs("gpurun_out/r02", exist_ok=True)
-json.dump(res, open("gpurun_out/r02/tok_ab.json", "w"), indent=1)
+os.makedirs("gpurun_out/r03", exist_ok=True)
+json.dump(res, open(os.environ.get("OUT", "gpurun_out/r03/tok_ab.json"), "w"), indent=1)
