@@ -103,7 +103,22 @@ typedef struct {
     const float* bias_f32;
     float* stats_out;
     int stats_ld;
+    /* ABI 3 - statistics by 256-column TILE, finalized inside the consumer (no seedmi_layernorm_stats_finalize launch in between).
+     * Producer: stats_by_tile = 1 writes ceil(N / 256) planes [plane][stats_ld][2] (one (sum, sum of squares) pair per row and n-tile, the
+     * four 64-column spans of a tile summed in span order: deterministic) instead of N / 64 span planes; stats_ld must be even.
+     * Consumer: ln_planes > 0 says ln_stats points at such planes (ln_planes of them, ln_ld rows each, over ln_cols columns in all) and not
+     * at finished (mean, rstd) pairs: every tile sums its rows' ln_planes pairs in plane order and forms
+     * mean = sum / ln_cols, rstd = rsqrt(max(sumsq / ln_cols - mean^2, 0) + ln_eps) itself.  ln_planes <= 6.
+     * Both need the 256x256 kernel (large M): seedmi_gemm_tile_stats_supported(M, N) says whether a call of that shape takes it. */
+    int stats_by_tile;
+    int ln_planes;
+    int ln_ld;
+    int ln_cols;
+    float ln_eps;
 } seedmi_gemm_ext_t;
+/* 1 if seedmi_gemm_bf16_ext(M, N, ...) runs on the 256x256 persistent kernel under the current options (the precondition of
+ * stats_by_tile / ln_planes), else 0. */
+int seedmi_gemm_tile_stats_supported(int M, int N);
 int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda, const void* W, int ldw, const void* bias,
                          const void* residual, int ldr, int epilogue, void* C, int ldc, int row_group, int row_extra,
                          const seedmi_gemm_ext_t* ext, void* workspace, size_t workspace_bytes, void* stream);

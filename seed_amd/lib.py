@@ -25,7 +25,8 @@ class VitLayer(C.Structure):
 
 
 class GemmExt(C.Structure):
-    _fields_ = [("ln_stats", _vp), ("ln_colsum", _vp), ("bias_f32", _vp), ("stats_out", _vp), ("stats_ld", _i)]
+    _fields_ = [("ln_stats", _vp), ("ln_colsum", _vp), ("bias_f32", _vp), ("stats_out", _vp), ("stats_ld", _i),
+                ("stats_by_tile", _i), ("ln_planes", _i), ("ln_ld", _i), ("ln_cols", _i), ("ln_eps", C.c_float)]
 
 
 class QfLayer(C.Structure):
@@ -77,6 +78,7 @@ SIGNATURES = {
     "seedmi_gemm_workspace_bytes": (C.c_size_t, []),
     "seedmi_gemm_bf16_ext": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, C.POINTER(GemmExt), _vp, C.c_size_t,
                                   _vp]),
+    "seedmi_gemm_tile_stats_supported": (_i, [_i, _i]),
     "seedmi_layernorm_stats_bf16": (_i, [_vp, _i, _i, _i, C.c_float, _vp, _vp]),
     "seedmi_layernorm_stats_finalize": (_i, [_vp, _i, _i, _i, _i, C.c_float, _vp, _vp]),
     "seedmi_gemm_bf16_ws": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, C.c_size_t, _vp]),
