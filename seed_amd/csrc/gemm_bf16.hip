@@ -790,11 +790,21 @@ SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid
 //   bit 4: residual epilogue: the second half's residual rows are requested after TWO rows of the first half are finished (their
 //          registers are free by then) instead of after four, so that their HBM round trip runs under the other two rows' arithmetic.
 //   bit 5: the second-dispatched wave group (waves 4..7) runs at s_setprio 1 throughout (the CDNA guide's static form of T5).
+//   bit 6: TWO phases of 32 MFMAs per K-tile instead of four of 16 (not combined with bits 1-3).  The phase stamps of the four-phase loop
+//          (tools/gemm_phase_times.py, profiles/r03_call2_*.log) show every phase costing the partner's MFMA section (300-330 cycles for 16
+//          MFMAs) plus ~90 cycles of hand-over (barrier release + the fragment reads' tail): 8 x ~400 = 3200 cycles per K-tile against 2048
+//          of MFMA issue.  Phase a = rows mh0 x all 64 columns, phase b = rows mh1 x the same W fragments: half as many hand-overs, the same 64
+//          fragment registers.  The fragment reads are waited for BEFORE the phase's first barrier (the partner's 32-MFMA section is long enough
+//          to cover them), which (i) lets the MFMA section start the moment the barrier opens and (ii) allows a slot to be restaged one phase
+//          after its last read (CDNA guide, WAR rule): every LDS-DMA request gets two phases (~1300 cycles each) of flight,
+//              a(kt):  vmcnt(6) | reads A(mh0), W | request A-mh1(kt+1) (2)           b(kt):  vmcnt(2) | reads A(mh1) | request W(kt+2) (4), A-mh0(kt+2) (2)
+//          with A staged so that every wave owns one mh0 piece and one mh1 piece of each half-tile (rows 64 j + 8 w + ..).
 template <int EPI, bool LNF = false, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr bool PRIO = SEEDMI_GEMM_PRIO;
     constexpr bool PREWAIT = (SCHED & 1) != 0, WPRE = (SCHED & 2) != 0, ASPLIT = (SCHED & 4) != 0, WSPLIT = (SCHED & 8) != 0;
-    constexpr bool RES_EARLY = (SCHED & 16) != 0, STATIC_PRIO = (SCHED & 32) != 0;
+    constexpr bool RES_EARLY = (SCHED & 16) != 0, STATIC_PRIO = (SCHED & 32) != 0, TWOPH = (SCHED & 64) != 0;
+    static_assert(!TWOPH || (SCHED & 14) == 0, "the two-phase schedule has its own request placement");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -859,8 +869,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = 128 * h + 16 * wave + 8 * j + (ln >> 3);       // row inside the 256-row tile
+                // TWOPH: a wave's A piece j is 8 rows of the mh0 (j = 0) / mh1 (j = 1) half of the half-tile: rows 64 j + 8 w + ..
+                const int rowA = TWOPH ? 128 * h + 64 * j + 8 * wave + (ln >> 3) : row;
                 const int cs = ln & 7;
-                offA[h][j] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(row));
+                offA[h][j] = (uint32_t)min(m0 + rowA, p.M - 1) * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(rowA));
                 offW[h][j] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldw + 8u * (uint32_t)(cs ^ swzW(row));
             }
     };
@@ -873,12 +885,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
     f32x4 acc[8][4];
     auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
-        char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
+        char* base = smem + (kt & 1) * KT_BYTES + (TWOPH ? wave * 1024 : wave * 2048);
         const int k0 = kt * BK;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
+            for (int j = 0; j < 2; ++j) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES + (TWOPH ? j * 8192 : j * 1024));
+    };
+    auto stageA_rows = [&](int kt, int j) {  // TWOPH: this wave's mh0 (j = 0) or mh1 (j = 1) piece of both A half-tiles
+        char* base = smem + (kt & 1) * KT_BYTES + wave * 1024 + j * 8192;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES);
     };
     auto stageA_half = [&](int kt, int h) {  // one A half-tile of K-tile kt (ASPLIT)
         char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
@@ -916,7 +934,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
         stageA(kb);
         stageW(kb);
-        if (kb + 1 < ke) stageW(kb + 1);
+        if (kb + 1 < ke) {
+            stageW(kb + 1);
+            if (TWOPH) stageA_rows(kb + 1, 0);
+        }
     };
     set_tile(s_tile);
     issue_prologue(s_kb, s_ke);
@@ -1112,6 +1133,72 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #endif
     };
 
+    // ---- TWOPH: one K-tile in two phases of 32 MFMAs (see the SCHED notes above the kernel)
+    auto ktile2 = [&](const int kt, const int kb, const int ke) {
+        const char* sb = smem + (kt & 1) * KT_BYTES;
+        const char* pa0 = sb + rdA0;                    // k-step 0
+        const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
+        const char* pw0 = sb + rdW0;
+        const char* pw1 = sb + (rdW0 ^ 64);
+        // ================= phase a: rows mh0 x (nh0, nh1) =================
+        // A-mh1(kt), requested in phase a of kt-1, is read in phase b: everything but the six requests of phase b of kt-1 must have landed
+        // (the segment's first K-tile came with the prologue and was waited for at the tile's opening)
+        if (kt > kb) {
+            if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(pw0 + t * 512); fw0[2 + t] = *(const bf16x8*)(pw1 + t * 512); }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { fw1[t] = *(const bf16x8*)(pw0 + (2 + t) * 512); fw1[2 + t] = *(const bf16x8*)(pw1 + (2 + t) * 512); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
+        if (kt + 1 < ke) stageA_rows(kt + 1, 1);        // mh1 rows of the other parity: last read in phase b of kt-1, retired before its barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        SEEDMI_SCHED_FENCE();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
+            }
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        // ================= phase b: rows mh1 x the same W fragments =================
+        // W(kt+1) and A-mh0(kt+1) (phase b of kt-1, or the prologue) are read in phase a of kt+1: only this K-tile's two requests stay in flight
+        if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
+        if (kt + 2 < ke) {                              // this parity's W and mh0 rows were last read in phase a, retired before its barrier
+            stageW(kt + 2);
+            stageA_rows(kt + 2, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+        SEEDMI_SCHED_FENCE();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
+            }
+        SEEDMI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();
+    };
+
     for (;;) {
     const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
     const int fold_cur = fold_par ^ 1;                  // ... and its fold operand set
@@ -1162,8 +1249,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // first K-tile complete (the up-to-4 youngest VM ops are the second W's LDS-DMA or the previous tile's epilogue stores).
     // PREWAIT: the previous tile's epilogue has waited for it already, ahead of its stores, which may still be on their way.
     if (!(PREWAIT && pre_waited)) {
-        if (ke - kb > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ke - kb > 1) {
+            if (TWOPH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // (+ the two A-mh0 requests of the second K-tile)
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     pre_waited = false;
     __builtin_amdgcn_s_barrier();
@@ -1177,7 +1268,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // compute.  It walks the same barriers and issues its share of the LDS-DMA, but reads no fragments and issues no MFMA: the tile's
     // live waves keep the LDS bandwidth and the power budget to themselves (proj -2 %, fc2 -2.9 % at B = 256).
     const bool live = (en0 + 64 * wn) < p.N;
-    if (live) {
+    if (live && TWOPH) {
+        for (int kt = kb; kt < ke; ++kt) ktile2(kt, kb, ke);
+    } else if (!live && TWOPH) {
+        // same requests, waits and barriers as ktile2, no fragment reads, no MFMA
+        for (int kt = kb; kt < ke; ++kt) {
+            if (kt > kb) {
+                if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (kt + 1 < ke) stageA_rows(kt + 1, 1);
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (kt + 2 < ke) {
+                stageW(kt + 2);
+                stageA_rows(kt + 2, 0);
+            }
+            SEEDMI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
+    } else if (live) {
         if (WPRE) {
             // W(nh0) of the segment's first K-tile (every later one is read in the P4 in front of it); the two fragment sets swap roles per K-tile
             const char* sb = smem + (kb & 1) * KT_BYTES;
@@ -1240,8 +1353,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     auto hook = [&]() {
         if (late) start_next();
         if (PREWAIT && more) {
-            if (s_ke - s_kb > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (the second W's four requests stay in flight)
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s_ke - s_kb > 1) {
+                if (TWOPH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // (the second K-tile's W and A-mh0 requests stay in flight)
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // (the second W's four requests stay in flight)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             pre_waited = true;
         }
     };
@@ -1361,6 +1478,8 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
             case 15: return launch_gemm256_sched<EPI, LNF, 15>(p, stream, sk_ws, sk_ws_bytes);
             case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);
             case 63: return launch_gemm256_sched<EPI, LNF, 63>(p, stream, sk_ws, sk_ws_bytes);
+            case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);
+            case 113: return launch_gemm256_sched<EPI, LNF, 113>(p, stream, sk_ws, sk_ws_bytes);
 #endif
             default: break;
         }
@@ -1425,7 +1544,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= 0 && value <= 63) {       // (values without a compiled variant run schedule 0)
+    if (key && !strcmp(key, "gemm_sched") && value >= 0 && value <= 127) {       // (values without a compiled variant run schedule 0)
         g_gemm_sched = value;
         return SEEDMI_OK;
     }
@@ -1475,6 +1594,15 @@ extern "C" int seedmi_set_option(const char* key, int value) {
 // ((code << 56) | s_memtime; waves 0 and 4), or null to stop
 extern "C" int seedmi_gemm_phase_timing(void* buf) { g_gemm_dbg = (unsigned long long*)buf; return SEEDMI_OK; }
 #endif
+
+// does seedmi_gemm_bf16_ext(M, N, ...) take the persistent 256x256 kernel under the current options (launch_gemm's rule)?
+static bool gemm_uses_256(int M, int N) {
+    const long long tiles256 = (long long)((M + B2 - 1) / B2) * ((N + B2 - 1) / B2);
+    const bool big = M >= 1024 && N >= 256 && tiles256 >= g_gemm_min_tiles;
+    const int variant = g_gemm_variant;
+    return variant == 256 || (variant == 0 && big);
+}
+extern "C" int seedmi_gemm_tile_stats_supported(int M, int N) { return (M > 0 && N > 0 && (N % 64) == 0 && gemm_uses_256(M, N)) ? 1 : 0; }
 
 extern "C" size_t seedmi_gemm_workspace_bytes(void) {
     // stream-K tail of the persistent 256x256 kernel: a flag word and one fp32 accumulator image (256 KiB) per workgroup

@@ -77,7 +77,6 @@ for name, M, N, K, epi in SHAPES:
                 rows = bad.any(1).nonzero().flatten()
                 print(f"!! {name} sched {v}: {int(bad.sum())} elements differ, rows {rows[:8].tolist()} ... of {rows.numel()} rows; "
                       f"cols {bad.any(0).nonzero().flatten()[:8].tolist()}", flush=True)
-    del ref_c, ref_aux
     times = {v: [] for v in SCHEDS}
     for r in range(ROUNDS + 1):
         for v in SCHEDS:
@@ -91,6 +90,13 @@ for name, M, N, K, epi in SHAPES:
             torch.cuda.synchronize()
             if r > 0:
                 times[v].append(e0.elapsed_time(e1) / REPS)
+            # race screen: the LAST of the back-to-back launches (every CU busy, requests in flight across tile boundaries) must still be
+            # bit-identical - a rare early read / late restage of an LDS slot shows up here, not in a lone launch
+            same = bool(torch.equal(C.view(torch.int16), ref_c.view(torch.int16))) and \
+                (aux is None or bool(torch.equal(aux.view(torch.int32), ref_aux.view(torch.int32))))
+            if not same:
+                ok[v] = False
+                print(f"!! {name} sched {v}: output of launch {REPS} of round {r} differs from schedule 0", flush=True)
     row = {}
     for v in SCHEDS:
         med, mn = statistics.median(times[v]), min(times[v])
@@ -98,7 +104,7 @@ for name, M, N, K, epi in SHAPES:
                                "bit_identical_to_sched_0": ok[v]}
     res[name] = row
     print(name, json.dumps(row), flush=True)
-    del A, W, C
+    del A, W, C, ref_c, ref_aux
 lib.seedmi_set_option(b"gemm_sched", 0)
 os.makedirs(os.path.dirname(OUT) or ".", exist_ok=True)
 json.dump(res, open(OUT, "w"), indent=1)
