@@ -50,7 +50,11 @@ std::atomic<int> g_gemm_streamk{1};  // "gemm_streamk": stream-K tail when the c
 std::atomic<int> g_gemm_prefetch_r{0};   // "gemm_prefetch_residual": residual tile touched during the K loop (measured neutral: off)
 std::atomic<int> g_gemm_residual_nt{1};  // "gemm_residual_nt": streaming stores for the BIAS_RESIDUAL output
 std::atomic<int> g_gemm_variant{0};  // "gemm": 0 = auto, 128 / 256 = force a kernel
-std::atomic<int> g_gemm_sched{0};    // "gemm_sched": schedule variant of the 256x256 kernel (bits: see gemm256_kernel), ViT epilogues only
+// "gemm_sched": schedule variant of the 256x256 kernel (bits: see gemm256_kernel) for the three ViT epilogues.  31 = every measured gain of
+// round 3 (epilogue-side wait, W pre-read, two LDS-DMA requests per phase with counted waits, early residual requests): bit-identical to
+// schedule 0, +3..5 % per GEMM, +3.4 % end to end (profiles/r03_gemm_sched_ab_call*.json).  0 = the round-2 schedule.
+constexpr int GEMM_SCHED_DEFAULT = 31;
+std::atomic<int> g_gemm_sched{GEMM_SCHED_DEFAULT};
 #ifdef SEEDMI_DEVTOOLS
 unsigned long long* g_gemm_dbg = nullptr;   // seedmi_gemm_phase_timing: device buffer for the phase clock stamps
 #endif
@@ -85,7 +89,12 @@ struct GemmParams {
     const float* ln_colsum;
     const float* bias_f32;
     float* stats_out;
-    int stats_ld;               // spans per row
+    int stats_ld;               // rows per plane
+    // statistics by 256-column tile (256x256 kernel only, see seedmi_gemm_ext_t): the producer writes one pair per row and n-tile; the consumer
+    // receives ln_planes partial planes in ln_stats (ln_ld rows each) and forms (mean, rstd) itself
+    int stats_by_tile;
+    int ln_planes, ln_ld;
+    float ln_inv_cols, ln_eps;
     int prefetch_residual;      // BIAS_RESIDUAL on the 256x256 kernel: touch the residual tile during the K loop ("gemm_prefetch_residual")
     int residual_nt;            // BIAS_RESIDUAL output stores: 1 = streaming (non-temporal), 0 = ordinary ("gemm_residual_nt")
     int row_group, row_extra;   // patch-embed: out_row = m + (m / row_group) * row_extra + row_extra ; res_row = m % row_group + row_extra
@@ -529,7 +538,7 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
         finish_row(4 + mi, mi, oa, oc);
         store_row(4 + mi, oa, oc);
     }
-    if (STATS) {
+    if (STATS && !p.stats_by_tile) {                  // (by tile: the workgroup sums its four spans after the tile - combine_tile_stats)
         // the wave's 128 (sum, sum of squares) pairs of this span: 1 KiB contiguous in the span's plane, two 512-byte store instructions
         // (lane id taken here, by volatile asm: derived from threadIdx up front it is one more value held across the whole tile, and
         // what hipcc then spills is reloaded right here, behind the tile's stores)
@@ -732,7 +741,14 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 // Raw s_barrier (not __syncthreads) so LDS-DMA stays in flight across barriers; waits are explicit.
 constexpr int B2 = 256;
 constexpr int SK_FLAGS_WORDS = 1024;               // stream-K flag area: one word per workgroup, the last one a sticky error word
-constexpr int MAX_SEGS = 512;                     // segment list of one workgroup in LDS (6 KiB)
+constexpr int MAX_SEGS = 128;                     // segment list of one workgroup in LDS (1.5 KiB; the launcher keeps tiles / workgroup below it)
+// LayerNorm fold, consumer side: LDS behind the scratch rows = two sets of (column sums 1 KiB | folded bias 1 KiB) for this tile / the next
+// one, then FIN = (mean, rstd) of the tile's 256 rows (2 KiB), then X (12 KiB) = the second FIN buffer when the statistics arrive finished
+// (they are requested while slower waves may still read the current tile's), or the tile's up to six partial planes (2 KiB each) when the
+// tile finalizes them itself.  Producer side: eight 1 KiB wave-private rows of (sum, sum of squares) pairs.
+constexpr int FOLD_SET_BYTES = 2048, FOLD_FIN_OFF = 2 * FOLD_SET_BYTES, FOLD_X_OFF = FOLD_FIN_OFF + 2048, FOLD_MAX_PLANES = 6;
+constexpr int FOLD_LDS_BYTES = FOLD_X_OFF + FOLD_MAX_PLANES * 2048;     // 18 KiB
+constexpr int STAT_PARK_BYTES = 8 * 1024;
 constexpr int SEG_BYTES = MAX_SEGS * 3 * 4;
 constexpr int SCRATCH_BYTES = 8 * 256;            // one 256-byte LDS-DMA landing row per wave (residual prefetch touches)
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
@@ -924,12 +940,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         if (FOLD_IN) {
             // the tile's fold operands travel with its first K-tile, as its OLDEST LDS-DMA request (one 1 KiB piece per wave, waves
             // 4-7 repeat pieces 0-3): complete, and published by the K loop's barriers, long before the epilogue reads them
-            const int piece = wave & 3;
-            const char* src;
-            if (piece == 0) src = (const char*)p.ln_colsum + 4u * (uint32_t)min(n0 + 4 * lane, p.N - 4);
-            else if (piece == 1) src = (const char*)p.bias_f32 + 4u * (uint32_t)min(n0 + 4 * lane, p.N - 4);
-            else src = (const char*)p.ln_stats + 8u * (uint32_t)min(m0 + 128 * (piece - 2) + 2 * lane, (p.M - 1) & ~1);
-            glds16((const bf16_t*)src, smem + STAT_OFF + fold_par * 4096 + piece * 1024);
+            // pieces: 0 column sums, 1 folded bias, then the statistics of the tile's 256 rows in 1 KiB halves (128 rows x 8 B): finished
+            // (mean, rstd) pairs (2 pieces) or ln_planes partial planes (2 pieces each); wave w takes pieces w, w + 8
+            const int ln = SCHED != 0 ? fresh_lane() : lane;
+            const int npieces = 2 + 2 * (p.ln_planes > 0 ? p.ln_planes : 1);
+            for (int pc = wave; pc < npieces; pc += 8) {
+                const char* src;
+                char* dst;
+                if (pc < 2) {
+                    src = (const char*)(pc == 0 ? p.ln_colsum : p.bias_f32) + 4u * (uint32_t)min(n0 + 4 * ln, p.N - 4);
+                    dst = smem + STAT_OFF + fold_par * FOLD_SET_BYTES + pc * 1024;
+                } else {
+                    const int q = pc - 2, half = q & 1;
+                    const uint32_t row = (uint32_t)min(m0 + 128 * half + 2 * ln, (p.M - 1) & ~1);
+                    if (p.ln_planes > 0) {
+                        src = (const char*)p.ln_stats + 8 * ((size_t)(q >> 1) * (size_t)p.ln_ld + row);
+                        dst = smem + STAT_OFF + FOLD_X_OFF + q * 1024;
+                    } else {
+                        src = (const char*)p.ln_stats + 8u * row;
+                        dst = smem + STAT_OFF + (fold_par ? FOLD_X_OFF : FOLD_FIN_OFF) + half * 1024;
+                    }
+                }
+                glds16((const bf16_t*)src, dst);
+            }
             fold_par ^= 1;
         }
         stageA(kb);
@@ -950,7 +983,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // a stamp is ISSUED into its own SGPR pair and nothing waits for it inside the stamped K-tile; the sixteen stamps of a K-tile are
     // written to LDS (no VM operation: the vmcnt pipeline is untouched) in the NEXT, unstamped K-tile, behind that K-tile's own first
     // lgkmcnt(0).  Dumped to global memory at the kernel's end.
-    constexpr int DBG_OFF = STAT_OFF + (LNF ? 8 * 1024 : 0);
+    // (consumers: inside the X area, behind the second FIN buffer - the stamped runs pass finished statistics; producers: behind the parks)
+    constexpr int DBG_OFF = STAT_OFF + (FOLD_IN ? FOLD_X_OFF + 2048 : (LNF ? STAT_PARK_BYTES : 0));
     const bool dbg_wave = p.dbg != nullptr && blockIdx.x == 0 && (wave & 3) == 0;
     char* const dbg_lds = smem + DBG_OFF + (wave >> 2) * 2048;
     int dbg_n = 0, dbg_tile = 0;
@@ -1133,6 +1167,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #endif
     };
 
+    // ---- statistics by tile.  Producer: the tile's eight waves have parked (sum, sum of squares) of their 128 rows x 64 columns in LDS;
+    //      once every wave has passed a barrier behind its epilogue, wave w sums the (up to four live) spans of rows 32 w .. 32 w + 31 in span
+    //      order and writes ONE pair per row into the tile's plane.  Done at the opening barrier of the NEXT tile (or behind the last one).
+    constexpr bool STATS_OUT = LNF && EPI == EPI_BIAS_RESIDUAL;
+    bool stats_pending = false;
+    int sp_m0 = 0, sp_n0 = 0;
+    auto combine_tile_stats = [&]() {
+        const int ln = fresh_lane();
+        if (ln < 32) {
+            const int r = 32 * wave + ln;                                   // row of the tile
+            const char* park = smem + STAT_OFF + (r >> 7) * 4096 + 8 * (r & 127);   // wave 4 (r >> 7) + wn parks at + 1024 wn
+            const int nlive = min(4, (p.N - sp_n0 + 63) >> 6);
+            float s1 = 0.f, s2 = 0.f;
+            for (int wq = 0; wq < nlive; ++wq) { const float2 t = *(const float2*)(park + 1024 * wq); s1 += t.x; s2 += t.y; }
+            const int m = sp_m0 + r;
+            if (m < p.M) *(float2*)(p.stats_out + ((size_t)(sp_n0 >> 8) * p.stats_ld + m) * 2) = make_float2(s1, s2);
+        }
+        stats_pending = false;
+    };
+    //      Consumer: the tile's partial planes have landed with its first K-tile; wave w turns rows 32 w .. of them into (mean, rstd) for the
+    //      fold pass at the end of the K loop (same arithmetic as seedmi_layernorm_stats_finalize: planes summed in order)
+    auto finalize_tile_stats = [&]() {
+        const int ln = fresh_lane();
+        if (ln < 32) {
+            const int r = 32 * wave + ln;
+            const char* src = smem + STAT_OFF + FOLD_X_OFF + (r >> 7) * 1024 + 8 * (r & 127);
+            float s1 = 0.f, s2 = 0.f;
+            for (int pl = 0; pl < p.ln_planes; ++pl) { const float2 t = *(const float2*)(src + 2048 * pl); s1 += t.x; s2 += t.y; }
+            const float mean = s1 * p.ln_inv_cols;
+            const float var = fmaxf(s2 * p.ln_inv_cols - mean * mean, 0.f);
+            *(float2*)(smem + STAT_OFF + FOLD_FIN_OFF + 8 * r) = make_float2(mean, rsqrtf(var + p.ln_eps));
+        }
+    };
+
     // ---- TWOPH: one K-tile in two phases of 32 MFMAs (see the SCHED notes above the kernel)
     auto ktile2 = [&](const int kt, const int kb, const int ke) {
         const char* sb = smem + (kt & 1) * KT_BYTES;
@@ -1257,7 +1325,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
     }
     pre_waited = false;
+    if (STATS_OUT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the previous tile's parked statistics are in LDS)
     __builtin_amdgcn_s_barrier();
+    if (STATS_OUT && stats_pending) combine_tile_stats();
+    if (FOLD_IN && p.ln_planes > 0) finalize_tile_stats();
     if (wm == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
     SEEDMI_SCHED_FENCE();
 #ifdef SEEDMI_DEVTOOLS
@@ -1334,8 +1405,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // the epilogue it cost 110-290 B of scratch per lane, reloaded behind the tile's stores)
         FoldLds fold;
         const int ln = SCHED != 0 ? fresh_lane() : lane;
-        fold.cs = smem + STAT_OFF + fold_cur * 4096 + 4 * (64 * wn + 16 * (ln >> 4));
-        fold.st = smem + STAT_OFF + fold_cur * 4096 + 2048 + 8 * (128 * wm + (ln & 15));
+        fold.cs = smem + STAT_OFF + fold_cur * FOLD_SET_BYTES + 4 * (64 * wn + 16 * (ln >> 4));
+        fold.st = smem + STAT_OFF + ((p.ln_planes > 0 || fold_cur == 0) ? FOLD_FIN_OFF : FOLD_X_OFF) + 8 * (128 * wm + (ln & 15));
         fold_accumulators(acc, fold);
         SEEDMI_SCHED_FENCE();
     }
@@ -1396,12 +1467,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             hook();
             if (acc[0][0][0] == 123.456f) p.C[0] = 0;       // keep the accumulators alive
         }
+        // (every wave of the workgroup, also those whose span lies beyond N and parked nothing: the combine is a workgroup job)
+        if (STATS_OUT && p.stats_by_tile) { stats_pending = true; sp_m0 = em0; sp_n0 = en0; }
     }
 #ifdef SEEDMI_DEVTOOLS
     if (GSTAMP_ON) { GSTAMP(2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); GSTAMP_STORE(0, 3, 101); }
     ++dbg_tile;
 #endif
     if (!more) break;
+    }
+    if (STATS_OUT && stats_pending) {                   // the last tile's statistics
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        combine_tile_stats();
     }
 #ifdef SEEDMI_DEVTOOLS
     if (dbg_wave) {                                     // dump: [2 stamped waves][256] x u64
@@ -1434,11 +1512,14 @@ std::atomic<unsigned> g_sk_epoch{0};
 template <int EPI, bool LNF, int SCHED>
 int launch_gemm256_sched(GemmParams p, hipStream_t stream, void* sk_ws, size_t sk_ws_bytes) {
 #ifdef SEEDMI_DEVTOOLS
-    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES + (LNF ? 8 * 1024 : 0) + 4096;     // + phase stamps
+    constexpr bool fold_in = LNF && EPI != EPI_BIAS_RESIDUAL;
+    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES + (fold_in ? FOLD_LDS_BYTES : (LNF ? STAT_PARK_BYTES + 4096 : 4096));   // (+ phase stamps)
     p.dbg = g_gemm_dbg;
 #else
-    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES + (LNF ? 8 * 1024 : 0);
+    constexpr bool fold_in = LNF && EPI != EPI_BIAS_RESIDUAL;
+    constexpr int lds = 2 * KT_BYTES + GELU_LUT_BYTES + SEG_BYTES + SCRATCH_BYTES + (fold_in ? FOLD_LDS_BYTES : (LNF ? STAT_PARK_BYTES : 0));
 #endif
+    static_assert(lds <= 160 * 1024, "LDS budget of the 256x256 kernel");
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
@@ -1473,13 +1554,13 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
 #ifdef SEEDMI_SCHED_ONLY                               // (register-pressure experiments: one variant, short compile)
             case SEEDMI_SCHED_ONLY: return launch_gemm256_sched<EPI, LNF, SEEDMI_SCHED_ONLY>(p, stream, sk_ws, sk_ws_bytes);
 #else
-            case 7: return launch_gemm256_sched<EPI, LNF, 7>(p, stream, sk_ws, sk_ws_bytes);
-            case 13: return launch_gemm256_sched<EPI, LNF, 13>(p, stream, sk_ws, sk_ws_bytes);
-            case 15: return launch_gemm256_sched<EPI, LNF, 15>(p, stream, sk_ws, sk_ws_bytes);
             case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);
+#ifdef SEEDMI_DEVTOOLS                                 // measured steps and the rejected two-phase schedule (tools/gemm_sched_ab.py)
+            case 7: return launch_gemm256_sched<EPI, LNF, 7>(p, stream, sk_ws, sk_ws_bytes);
+            case 15: return launch_gemm256_sched<EPI, LNF, 15>(p, stream, sk_ws, sk_ws_bytes);
             case 63: return launch_gemm256_sched<EPI, LNF, 63>(p, stream, sk_ws, sk_ws_bytes);
             case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);
-            case 113: return launch_gemm256_sched<EPI, LNF, 113>(p, stream, sk_ws, sk_ws_bytes);
+#endif
 #endif
             default: break;
         }
@@ -1544,7 +1625,8 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= 0 && value <= 127) {       // (values without a compiled variant run schedule 0)
+    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 127) {      // (-1 = the default; values without a compiled variant run schedule 0)
+        if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
         return SEEDMI_OK;
     }
@@ -1583,6 +1665,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
     if (key && !strcmp(key, "tokenize_lnfold") && seedmi_tokenizer_set_lnfold(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_split_rounds") && seedmi_tokenizer_set_split(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_vq_head") && seedmi_tokenizer_set_vqhead(value) == SEEDMI_OK) return SEEDMI_OK;
+    if (key && !strcmp(key, "tokenize_tile_stats") && seedmi_tokenizer_set_tilestats(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_llama_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_attn_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);
@@ -1624,6 +1707,15 @@ extern "C" int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda,
                 (((uintptr_t)ext->ln_colsum | (uintptr_t)ext->bias_f32) & 15) || ((uintptr_t)ext->ln_stats & 7))) {
         seedmi_set_error("seedmi_gemm_bf16_ext: the LayerNorm fold needs ln_stats, ln_colsum, bias_f32 (16-byte aligned), N %% 64 == 0 and the BIAS or BIAS_GELU epilogue");
         return SEEDMI_E_SHAPE;
+    }
+    if (ext && (ext->stats_by_tile || ext->ln_planes > 0)) {
+        const bool prod_ok = !ext->stats_by_tile || (ext->stats_out && (ext->stats_ld % 2) == 0);
+        const bool cons_ok = ext->ln_planes <= 0 || (lnf && ext->ln_planes <= FOLD_MAX_PLANES && ext->ln_ld >= M && (ext->ln_ld % 2) == 0 && ext->ln_cols > 0);
+        if (!prod_ok || !cons_ok || !gemm_uses_256(M, N)) {
+            seedmi_set_error("seedmi_gemm_bf16_ext: statistics by tile need the 256x256 kernel for this shape (seedmi_gemm_tile_stats_supported), "
+                             "an even stats_ld / ln_ld >= M, stats_out resp. ln_stats + ln_colsum + bias_f32, and ln_planes <= %d", FOLD_MAX_PLANES);
+            return SEEDMI_E_SHAPE;
+        }
     }
     if (ext && ext->stats_out && (epilogue != EPI_BIAS_RESIDUAL || (N % 64) || ext->stats_ld < M)) {
         seedmi_set_error("seedmi_gemm_bf16_ext: stats_out belongs to the BIAS_RESIDUAL epilogue and needs N %% 64 == 0 and stats_ld >= M");
@@ -1677,6 +1769,11 @@ extern "C" int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda,
     p.bias_f32 = lnf ? ext->bias_f32 : nullptr;
     p.stats_out = ext ? ext->stats_out : nullptr;
     p.stats_ld = ext ? ext->stats_ld : 0;
+    p.stats_by_tile = (ext && ext->stats_out) ? ext->stats_by_tile : 0;
+    p.ln_planes = (lnf && ext->ln_planes > 0) ? ext->ln_planes : 0;
+    p.ln_ld = p.ln_planes ? ext->ln_ld : 0;
+    p.ln_inv_cols = p.ln_planes ? 1.0f / (float)ext->ln_cols : 0.f;
+    p.ln_eps = p.ln_planes ? ext->ln_eps : 0.f;
     p.prefetch_residual = g_gemm_prefetch_r;
     p.residual_nt = g_gemm_residual_nt;
     p.row_group = row_group > 0 ? row_group : 1;

@@ -20,6 +20,7 @@ int seedmi_tokenizer_set_streamk(int v);
 int seedmi_tokenizer_set_lnfold(int v);
 int seedmi_tokenizer_set_split(int v);
 int seedmi_tokenizer_set_vqhead(int v);
+int seedmi_tokenizer_set_tilestats(int v);
 // seedmi_set_option("skinny_nt" | "skinny_waves", v): decode GEMM experiments (llama.hip)
 int seedmi_llama_set_option(const char* key, int value);
 int seedmi_attn_set_option(const char* key, int value);

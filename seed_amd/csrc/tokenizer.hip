@@ -38,6 +38,8 @@ struct TokWs {
 
 int g_tok_streamk = 0;                    // seedmi_set_option("tokenize_streamk", 0|1)
 int g_tok_split = 0;                      // seedmi_set_option("tokenize_split_rounds", 0|1): whole rounds of 256x256 tiles + a 128x128 remainder
+int g_tok_tilestats = 0;                  // seedmi_set_option("tokenize_tile_stats", 0|1): LayerNorm statistics by 256-column tile, finalized inside
+                                          // the consuming GEMM (no seedmi_layernorm_stats_finalize launches between the ViT GEMMs)
 int g_tok_vqhead = 1;                     // seedmi_set_option("tokenize_vq_head", 0|1): last head Linear fused into the VQ argmin kernel
 int g_tok_lnfold = 1;                     // seedmi_set_option("tokenize_lnfold", 0|1): LayerNorm folded into qkv / fc1 when the weights carry it
 
@@ -62,7 +64,7 @@ TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
     t.z = (bf16_t*)c.take(Mq * 64 * 2);
     t.spans = (int)((D + 63) / 64);
     t.stats = (float*)c.take((M + 1) * 2 * sizeof(float));      // (the fold's LDS-DMA reads row pairs: one row of slack)
-    t.spart = (float*)c.take(M * t.spans * 2 * sizeof(float));
+    t.spart = (float*)c.take((M + 1) * t.spans * 2 * sizeof(float));          // (+ 1: the by-tile planes keep an even row stride)
     t.sk_bytes = seedmi_gemm_workspace_bytes();
     t.sk = c.take(t.sk_bytes);
     t.bytes = c.off;
@@ -180,14 +182,29 @@ int run_phase(const Part& p, int phase) {
             seedmi_gemm_ext_t e_qkv = {t.stats, (const float*)L.qkv_cs, (const float*)L.qkv_bf, nullptr, 0};
             seedmi_gemm_ext_t e_fc1 = {t.stats, (const float*)L.fc1_cs, (const float*)L.fc1_bf, nullptr, 0};
             seedmi_gemm_ext_t e_res = {nullptr, nullptr, nullptr, t.spart, (int)M};
+            // Statistics by tile: where all four GEMMs of the block run on the 256x256 kernel (large sub-batches), proj / fc2 write one
+            // (sum, sum of squares) pair per row and n-tile (6 planes for D = 1408 instead of 22 span planes) and qkv / fc1 finalize the rows
+            // of each of their tiles themselves: the two seedmi_layernorm_stats_finalize launches per block - a 65 792-thread kernel queued
+            // behind the other stream's GEMM workgroups, on the critical path between two GEMMs of this stream - disappear.
+            // (Block 0's norm1 statistics come finished from the patch-embed phase.)
+            const bool by_tile = g_tok_tilestats && !g_tok_split && (D + 255) / 256 <= 6 && seedmi_gemm_tile_stats_supported((int)M, D) &&
+                                 seedmi_gemm_tile_stats_supported((int)M, 3 * D) && seedmi_gemm_tile_stats_supported((int)M, F);
+            if (by_tile) {
+                const int ld = ((int)M + 1) & ~1, planes = (D + 255) / 256;
+                e_res.stats_ld = ld;
+                e_res.stats_by_tile = 1;
+                seedmi_gemm_ext_t e_par = {t.spart, nullptr, nullptr, nullptr, 0, 0, planes, ld, D, 1e-6f};
+                e_fc1 = e_par; e_fc1.ln_colsum = (const float*)L.fc1_cs; e_fc1.bias_f32 = (const float*)L.fc1_bf;
+                if (phase > 0) { e_qkv = e_par; e_qkv.ln_colsum = (const float*)L.qkv_cs; e_qkv.bias_f32 = (const float*)L.qkv_bf; }
+            }
             CK(GEMM_R(M, 3 * D, D, t.x, D, L.qkv_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, &e_qkv));
             CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
                                      vit_scale, 0, 1, s));
             CK(GEMM_R(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, &e_res));
-            CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
+            if (!by_tile) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
             CK(GEMM_R(M, F, D, t.x, D, L.fc1_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, &e_fc1));
             CK(GEMM_R(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, &e_res));
-            if (phase + 1 < w->vit_depth) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
+            if (!by_tile && phase + 1 < w->vit_depth) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
             return SEEDMI_OK;
         }
         CK(seedmi_layernorm_bf16(t.x, D, L.ln1_w, L.ln1_b, 1e-6f, t.xn, D, M, D, s));
@@ -308,6 +325,11 @@ int seedmi_tokenizer_set_lnfold(int v) {
 int seedmi_tokenizer_set_split(int v) {
     if (v != 0 && v != 1) return SEEDMI_E_SHAPE;
     g_tok_split = v;
+    return SEEDMI_OK;
+}
+int seedmi_tokenizer_set_tilestats(int v) {
+    if (v != 0 && v != 1) return SEEDMI_E_SHAPE;
+    g_tok_tilestats = v;
     return SEEDMI_OK;
 }
 int seedmi_tokenizer_set_vqhead(int v) {

@@ -69,12 +69,16 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[128, 256], ids=["gemm128", "gemm256"])
+@pytest.fixture(params=[128, 256, (256, 0)], ids=["gemm128", "gemm256", "gemm256_sched0"])
 def gemm_variant(request, lib):
-    """Every GEMM parity test runs once per tile kernel (128x128 two-barrier and 256x256 staggered deep pipeline)."""
-    L.check(lib.seedmi_set_option(b"gemm", request.param), "set_option")
-    yield request.param
+    """Every GEMM parity test runs once per tile kernel (128x128 two-barrier and 256x256 staggered deep pipeline), the 256x256 kernel
+    under its default schedule (gemm_sched 31, round 3) and under the round-2 schedule (0) that stays selectable."""
+    variant, sched = request.param if isinstance(request.param, tuple) else (request.param, -1)
+    L.check(lib.seedmi_set_option(b"gemm", variant), "set_option")
+    L.check(lib.seedmi_set_option(b"gemm_sched", sched), "set_option")
+    yield variant
     lib.seedmi_set_option(b"gemm", 0)
+    lib.seedmi_set_option(b"gemm_sched", -1)
 
 
 GEMM_SHAPES = [
@@ -301,6 +305,102 @@ def test_gemm_residual_emits_layernorm_statistics(lib, gemm_variant):
     assert torch.allclose(part[:, :, 0].sum(0).cpu().double(), y.sum(1), rtol=1e-5, atol=1e-3)
     assert torch.allclose(stats[:, 0].cpu().double(), y.mean(1), rtol=1e-4, atol=1e-5)
     assert torch.allclose(stats[:, 1].cpu().double(), torch.rsqrt(y.var(1, unbiased=False) + 1e-6), rtol=1e-4)
+
+
+@pytest.mark.parametrize("sched", [0, 31], ids=["sched0", "sched31"])
+def test_layernorm_statistics_by_tile_with_outlier_channels(lib, sched):
+    """The LayerNorm fold chain as the tokenizer runs it at large batch (eva_vit.py:199-202): proj / fc2 (BIAS_RESIDUAL) emit one
+    (sum, sum of squares) pair per row and 256-column TILE, the consuming qkv / fc1 GEMM finalizes its tiles' rows itself - no
+    seedmi_layernorm_stats_finalize launch - on a residual stream with MASSIVE-ACTIVATION channels (|x| ~ 300 in three channels with a
+    small gamma, plus rows with a large common mean: where the one-pass variance E[x^2] - mean^2 and the mean * colsum cancellation of the
+    fold are weakest).  Checked: the tile planes against the span planes and fp64 sums; the in-kernel finalize against the
+    finalize kernel and against the two-pass seedmi_layernorm_stats_bf16; the folded GEMM from tile statistics against the explicit
+    LayerNorm -> GEMM path and the fp64 restatement (not further from it than the reference's own rounding choreography)."""
+    import ctypes
+    gen = torch.Generator().manual_seed(2024)
+    M, D, N2 = 257 * 32, 1408, 4224                       # 33 m-tiles: every GEMM of the chain takes the 256x256 kernel
+    assert lib.seedmi_gemm_tile_stats_supported(M, D) == 1 and lib.seedmi_gemm_tile_stats_supported(M, N2) == 1
+    eps = 1e-6
+    x_in = rand(gen, M, D)
+    hot = [7, 500, 1300]
+    x_in[:, hot] *= 300.0                                  # massive-activation channels
+    x_in[::5] += 40.0 * torch.rand(M, 1, generator=gen)[::5]      # rows with a large common mean
+    x_in = bf(x_in)
+    A = bf(rand(gen, M, D)).cuda()
+    Wp = bf(rand(gen, D, D, scale=0.03)).cuda()
+    bp = bf(rand(gen, D, scale=0.1)).cuda()
+    gamma = 1.0 + 0.2 * rand(gen, D)
+    gamma[hot] = 0.01                                      # what a trained block does to such channels
+    gamma, beta = bf(gamma), bf(rand(gen, D, scale=0.1))
+    W2 = bf(rand(gen, N2, D, scale=0.03))
+    b2 = bf(rand(gen, N2, scale=0.2))
+    Wg = bf(W2.float() * gamma.float())
+    cs = Wg.float().sum(1).cuda()
+    bfold = (b2.float() + W2.float() @ beta.float()).cuda()
+    L.check(lib.seedmi_set_option(b"gemm_sched", sched), "gemm_sched")
+    try:
+        xd = x_in.cuda()
+        ld = (M + 1) & ~1
+        planes = torch.full((6, ld, 2), float("nan"), dtype=torch.float32, device="cuda")
+        spans = torch.full((22, M, 2), float("nan"), dtype=torch.float32, device="cuda")
+        y_t = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
+        y_s = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
+        e_t = L.GemmExt(None, None, None, L.ptr(planes), ld, 1)
+        e_s = L.GemmExt(None, None, None, L.ptr(spans), M)
+        for ext, out in ((e_t, y_t), (e_s, y_s)):
+            L.check(lib.seedmi_gemm_bf16_ext(M, D, D, L.ptr(A), D, L.ptr(Wp), D, L.ptr(bp), L.ptr(xd), D, L.EPI_BIAS_RESIDUAL, L.ptr(out), D, 0, 0,
+                                             ctypes.byref(ext), None, 0, L.stream_ptr()), "producer")
+        torch.cuda.synchronize()
+        assert torch.equal(y_t, y_s)                       # the statistics layout does not touch the output
+        y = y_t.double().cpu()
+        pt, ps = planes[:, :M].double().cpu(), spans.double().cpu()
+        assert torch.isfinite(pt).all()
+        # a tile's pair is the sum of its (up to) four spans, in span order: EQUAL in fp32; all of them are the row's sums
+        for t in range(6):
+            acc = torch.zeros(M, 2, dtype=torch.float32)
+            for sp in range(4 * t, min(4 * t + 4, 22)):
+                acc += spans[sp].cpu()
+            assert torch.equal(planes[t, :M].cpu(), acc), f"tile plane {t} is not the in-order sum of its spans"
+        assert torch.allclose(pt.sum(0)[:, 0], y.sum(1), rtol=1e-5, atol=1e-2)
+        assert torch.allclose(pt.sum(0)[:, 1], (y * y).sum(1), rtol=1e-5)
+        # finished statistics three ways: finalize kernel on the span planes, two-pass kernel on y, fp64
+        st_fin = torch.empty(M + 1, 2, dtype=torch.float32, device="cuda")
+        st_two = torch.empty(M + 1, 2, dtype=torch.float32, device="cuda")
+        L.check(lib.seedmi_layernorm_stats_finalize(L.ptr(spans), 22, M, M, D, eps, L.ptr(st_fin), L.stream_ptr()), "finalize")
+        L.check(lib.seedmi_layernorm_stats_bf16(L.ptr(y_t), D, M, D, eps, L.ptr(st_two), L.stream_ptr()), "two-pass")
+        torch.cuda.synchronize()
+        mean64, rstd64 = y.mean(1), torch.rsqrt(y.var(1, unbiased=False) + eps)
+        for nm, st in (("one-pass (spans)", st_fin), ("two-pass", st_two)):
+            em = ((st[:M, 0].double().cpu() - mean64).abs() / (mean64.abs() + y.std(1))).max().item()
+            er = ((st[:M, 1].double().cpu() - rstd64).abs() / rstd64).max().item()
+            print(f"[outlier stats {nm}] max rel err: mean {em:.2e} rstd {er:.2e}")
+            assert em < 1e-5 and er < 2e-4, (nm, em, er)
+        # consumer: tile planes finalized inside the GEMM vs finished statistics vs explicit LayerNorm
+        Wgd, W2d, b2d = Wg.cuda(), W2.cuda(), b2.cuda()
+        z_tile = torch.zeros(M, N2, dtype=torch.bfloat16, device="cuda")
+        z_fin = torch.zeros(M, N2, dtype=torch.bfloat16, device="cuda")
+        e_c = L.GemmExt(L.ptr(planes), L.ptr(cs), L.ptr(bfold), None, 0, 0, 6, ld, D, eps)
+        e_f = L.GemmExt(L.ptr(st_fin), L.ptr(cs), L.ptr(bfold), None, 0)
+        for ext, out in ((e_c, z_tile), (e_f, z_fin)):
+            L.check(lib.seedmi_gemm_bf16_ext(M, N2, D, L.ptr(y_t), D, L.ptr(Wgd), D, None, None, 0, L.EPI_BIAS, L.ptr(out), N2, 0, 0,
+                                             ctypes.byref(ext), None, 0, L.stream_ptr()), "consumer")
+        xn = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.seedmi_layernorm_bf16(L.ptr(y_t), D, L.ptr(gamma.cuda()), L.ptr(beta.cuda()), eps, L.ptr(xn), D, M, D, L.stream_ptr()), "ln")
+        z_exp = run_gemm(lib, xn, W2d, b2d, None, L.EPI_BIAS)
+        torch.cuda.synchronize()
+        same = (z_tile.view(torch.int16) == z_fin.view(torch.int16)).float().mean().item()
+        print(f"[outlier fold] in-kernel finalize vs finalize kernel: {same:.6f} of the outputs bit-equal")
+        assert same > 0.999                                # (the two sums associate differently: the last ulp of rstd may differ)
+        rows = torch.arange(0, M, 7)                       # fp64 restatement on a row sample
+        ln64 = torch.nn.functional.layer_norm(y[rows], (D,), gamma.double(), beta.double(), eps)
+        want = ln64 @ W2.double().t() + b2.double()
+        def rel(t):
+            return ((t[rows.cuda()].double().cpu() - want).norm() / want.norm()).item()
+        e_tile, e_fin, e_exp = rel(z_tile), rel(z_fin), rel(z_exp)
+        print(f"[outlier fold] rel err vs fp64: fold from tile statistics {e_tile:.3e}, from finished statistics {e_fin:.3e}, explicit LayerNorm -> GEMM {e_exp:.3e}")
+        assert e_tile < max(1.2 * e_exp, 3e-3), (e_tile, e_exp)
+    finally:
+        lib.seedmi_set_option(b"gemm_sched", -1)
 
 
 def test_gemm_residual_inplace(lib, gemm_variant):

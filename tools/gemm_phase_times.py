@@ -102,4 +102,4 @@ for v in SCHEDS:
         if 100 in tile_ev and 101 in tile_ev:
             print(f"          tile: open->K loop left {tile_ev[101] - tile_ev[100]} | ->requests issued {tile_ev.get(102, 0) - tile_ev[101]} | "
                   f"->epilogue done {tile_ev.get(103, 0) - tile_ev.get(102, 0)}   (s_memtime cycles)")
-lib.seedmi_set_option(b"gemm_sched", 0)
+lib.seedmi_set_option(b"gemm_sched", -1)
