@@ -318,8 +318,20 @@ constexpr int V16_N = 257;
 constexpr int V16_P_OFF = VLDS_BYTES;                   // the side row: 288 halves (keys 272..287 stay zero)
 constexpr int V16_LDS_BYTES = VLDS_BYTES + 1024;
 
-template <bool ROUND_S>
+// MODE bit 0: the output tile leaves as three 16-byte stores per lane instead of six 8-byte ones (one v_permlane16_swap per dword joins the
+//             8-byte pieces of two lane groups: every store instruction then writes 64 contiguous bytes of each of its 16 rows).  The 96 / 51
+//             store instructions of an item all end up queued in the CU's one address unit at the end of the PV phase.
+//      bit 1: softmax normalisation moved behind PV.  P leaves the exponential UN-normalised (e = 2^((s - max) log2 e) <= 1, rounded to half)
+//             and the row sum comes out of the PV MFMAs themselves: the V image's 89th column (first pad column, never loaded: the staging
+//             skips the pad chunk) holds 1.0, so O^T row 88 = sum_k half(e_k) - exactly the sum of the values that were multiplied.
+//             O = O' / that sum: 24 multiplies instead of a 68-term sum, 68 multiplies and the reduction shuffles per tile; the exponent
+//             arguments are formed two at a time (v_pk_fma_f32).  ~270 instead of ~450 VALU instructions per tile, and the phase that
+//             holds them is VALU-bound.  This MOVES a rounding point: the reference rounds the normalised probabilities to half before PV
+//             (eva_vit.py:153-156 under autocast), here the un-normalised ones are rounded and the quotient is formed in fp32 - the same
+//             relative rounding error per term, normalised consistently; results differ from the other kernels in the last half ulp.
+template <bool ROUND_S, int MODE>
 __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParams p) {
+    constexpr bool WIDE = (MODE & 1) != 0, FLASH = (MODE & 2) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ksm = (bf16_t*)smem;
     bf16_t* Qsm = (bf16_t*)(smem + VKQ_BYTES);
@@ -336,17 +348,27 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
 
     for (int i = tid; i < V16_LDS_BYTES / 16; i += 64 * V16_WAVES) *(uint4*)(smem + 16 * i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    if (FLASH) {
+        // the V image's pad chunk (columns 88..95) of every row: {1, 0, ..}.  It sits at chunk position 11 ^ swizzle(row); the V staging
+        // below never writes it, so it is set once.
+        for (int r = tid; r < VNKP; r += 64 * V16_WAVES)
+            *(uint4*)((char*)Vsm + r * (VLD * 2) + 16 * ((VCHL - 1) ^ vswz(r))) = make_uint4(0x3f80u, 0, 0, 0);
+        __syncthreads();
+    }
 
-    auto stage = [&](const bf16_t* base, int ld, bf16_t* dst, int item) {
+    auto stage = [&](const bf16_t* base, int ld, bf16_t* dst, int item, bool skip_pad = false) {
         const int b = item / p.heads, h = item - b * p.heads;
         const bf16_t* src = base + (size_t)b * n * ld + h * VHD;
         const int lane = fresh_lane();
         for (int j = 0; j < my_pieces; ++j) {
             const int piece = wave + V16_WAVES * j;
-            const int q = min(64 * piece + lane, total_chunks - 1);  // LDS chunk position (clamped lanes rewrite the last one)
+            const int q0 = 64 * piece + lane;
+            const int q = min(q0, total_chunks - 1);                 // LDS chunk position (clamped lanes rewrite the last one)
             const int row = q / VCHL;
-            const int c = min((q - row * VCHL) ^ vswz(row), VCH - 1);   // source chunk of that position; the pad chunk copies the 11th
-            glds16v(src + (size_t)row * ld + 8 * c, (char*)dst + piece * 1024);
+            const int c0 = (q - row * VCHL) ^ vswz(row);
+            const int c = min(c0, VCH - 1);                          // source chunk of that position; the pad chunk copies the 11th
+            // (skip_pad: lanes that would write a pad chunk - or, clamped, re-write the last position - stay out: EXEC-masked LDS-DMA)
+            if (!skip_pad || (c0 < VCH && q0 < total_chunks)) glds16v(src + (size_t)row * ld + 8 * c, (char*)dst + piece * 1024);
         }
     };
 
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
     if (item >= p.items) return;
     stage(p.K, p.ldk, Ksm, item);
     stage(p.Q, p.ldq, Qsm, item);
-    stage(p.V, p.ldv, Vsm, item);
+    stage(p.V, p.ldv, Vsm, item, FLASH);
     const float L2E = 1.4426950408889634f;
 
     for (int it = 0;; ++it) {
@@ -419,6 +441,25 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float nmx = -mx * L2E;
+            if (FLASH) {
+                // un-normalised exponentials, arguments two at a time; the row sum is formed by the PV MFMAs (ones column of V)
+                const f32x2 l2 = {L2E, L2E}, nm2 = {nmx, nmx};
+#pragma unroll
+                for (int kk = 0; kk < VKK; ++kk) {
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int kt = 2 * kk + u;
+                        if (kt < VNT) {
+                            const f32x2 a0 = __builtin_elementwise_fma((f32x2){s[kt][0], s[kt][1]}, l2, nm2);
+                            const f32x2 a1 = __builtin_elementwise_fma((f32x2){s[kt][2], s[kt][3]}, l2, nm2);
+                            w[2 * u] = pack2bf(__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1]));
+                            w[2 * u + 1] = pack2bf(__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1]));
+                        }
+                    }
+                    pf[kk] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+                }
+            } else {
             float sum = 0.f;                                 // (one chain in (kt, r) order, like the 12-wave kernel: bit-identical rows)
 #pragma unroll
             for (int kt = 0; kt < VNT; ++kt)
@@ -442,6 +483,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                     pw.w = pack2bf(s[2 * kk + 1][2] * inv, s[2 * kk + 1][3] * inv);
                 }
                 pf[kk] = __builtin_bit_cast(bf16x8, pw);
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -493,9 +535,12 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                 t[kt] = __builtin_amdgcn_exp2f(fmaf(t[kt], L2E, nmx));
                 sum += t[kt];
             }
+            float inv = 1.0f;                               // FLASH: the row leaves un-normalised, like the tiles
+            if (!FLASH) {
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-            const float inv = __builtin_amdgcn_rcpf(sum);
+                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                inv = __builtin_amdgcn_rcpf(sum);
+            }
             if (g == 0) {
 #pragma unroll
                 for (int kt = 0; kt < VNT; ++kt) Psm[16 * kt + li] = f2bf(t[kt] * inv);
@@ -530,16 +575,34 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
         };
         auto store_o = [&](const f32x4 (&o)[VHT], int qtile, bool first_row_only) {
             const int sl = fresh_lane(), g = sl >> 4;
-            if (first_row_only && (sl & 15) != 0) return;
-            bf16_t* op = p.O + ((size_t)b * n + 16 * qtile + (sl & 15)) * p.ldo + h * VHD;
+            float inv = 1.0f;
+            if (FLASH) {
+                // O^T row 88 (= 16 * 5 + 4 * 2 + 0: tile nn = 5, lane group 2, register 0) is the row sum of the query in column li
+                const float rs = __shfl(o[VHT - 1][0], (sl & 15) + 32, 64);
+                inv = __builtin_amdgcn_rcpf(rs);
+            }
+            uint2 w[VHT];
 #pragma unroll
             for (int nn = 0; nn < VHT; ++nn) {
-                const int c0 = 16 * nn + 4 * g;
-                if (c0 + 4 <= VHD) {
-                    uint2 w;
-                    w.x = pack2bf(o[nn][0], o[nn][1]);
-                    w.y = pack2bf(o[nn][2], o[nn][3]);
-                    *(uint2*)(op + c0) = w;
+                w[nn].x = pack2bf(o[nn][0] * inv, o[nn][1] * inv);
+                w[nn].y = pack2bf(o[nn][2] * inv, o[nn][3] * inv);
+            }
+            bf16_t* op = p.O + ((size_t)b * n + 16 * qtile + (sl & 15)) * p.ldo + h * VHD;
+            if (WIDE) {
+                // tiles nn, nn + 1: after the swaps lane group g holds columns 16 (nn + (g & 1)) + 8 (g >> 1) .. + 7 as (x, y | x', y')
+#pragma unroll
+                for (int nn = 0; nn < VHT; nn += 2) {
+                    const auto tx = __builtin_amdgcn_permlane16_swap(w[nn].x, w[nn + 1].x, false, false);
+                    const auto ty = __builtin_amdgcn_permlane16_swap(w[nn].y, w[nn + 1].y, false, false);
+                    const int c0 = 16 * (nn + (g & 1)) + 8 * (g >> 1);
+                    if (c0 + 8 <= VHD && !(first_row_only && (sl & 15) != 0)) *(uint4*)(op + c0) = make_uint4(tx[0], ty[0], tx[1], ty[1]);
+                }
+            } else {
+                if (first_row_only && (sl & 15) != 0) return;
+#pragma unroll
+                for (int nn = 0; nn < VHT; ++nn) {
+                    const int c0 = 16 * nn + 4 * g;
+                    if (c0 + 4 <= VHD) *(uint2*)(op + c0) = w[nn];
                 }
             }
         };
@@ -594,7 +657,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // every wave is done with V(item) and the side row
-        stage(p.V, p.ldv, Vsm, next);
+        stage(p.V, p.ldv, Vsm, next, FLASH);
         item = next;
     }
 }
@@ -637,13 +700,18 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (g_attn_vit == 2 && nq == V16_N && round_scores) {        // (unrounded scores: only tests ask for them; the 12-wave kernel serves those)
+    if (g_attn_vit >= 2 && nq == V16_N && round_scores) {        // (unrounded scores: only tests ask for them; the 12-wave kernel serves those)
         static bool attr16_dev[SEEDMI_MAX_DEVICES] = {};
         if (!attr16_dev[dev]) {
-            (void)hipFuncSetAttribute((const void*)attn_vit16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)attn_vit16_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)attn_vit16_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)attn_vit16_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);
             attr16_dev[dev] = true;
         }
-        hipLaunchKernelGGL((attn_vit16_kernel<true>), dim3(grid), dim3(64 * V16_WAVES), V16_LDS_BYTES, (hipStream_t)stream, p);
+        const dim3 blk16(64 * V16_WAVES);
+        if (g_attn_vit == 2) hipLaunchKernelGGL((attn_vit16_kernel<true, 0>), dim3(grid), blk16, V16_LDS_BYTES, (hipStream_t)stream, p);
+        else if (g_attn_vit == 3) hipLaunchKernelGGL((attn_vit16_kernel<true, 1>), dim3(grid), blk16, V16_LDS_BYTES, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((attn_vit16_kernel<true, 3>), dim3(grid), blk16, V16_LDS_BYTES, (hipStream_t)stream, p);
         return seedmi_check_launch("attn_vit16");
     }
     const dim3 blk(64 * VWAVES);
