@@ -462,13 +462,18 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
             } else {
             float sum = 0.f;                                 // (one chain in (kt, r) order, like the 12-wave kernel: bit-identical rows)
 #pragma unroll
-            for (int kt = 0; kt < VNT; ++kt)
+            for (int kt = 0; kt < VNT; ++kt) {
+                // (exponent arguments two at a time - v_pk_fma_f32 - the same fma per element)
+                const f32x2 a0 = __builtin_elementwise_fma((f32x2){s[kt][0], s[kt][1]}, (f32x2){L2E, L2E}, (f32x2){nmx, nmx});
+                const f32x2 a1 = __builtin_elementwise_fma((f32x2){s[kt][2], s[kt][3]}, (f32x2){L2E, L2E}, (f32x2){nmx, nmx});
+                const float arg[4] = {a0[0], a0[1], a1[0], a1[1]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], L2E, nmx));
+                    const float e = __builtin_amdgcn_exp2f(arg[r]);
                     s[kt][r] = e;
                     sum += e;
                 }
+            }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float inv = __builtin_amdgcn_rcpf(sum);
@@ -662,7 +667,12 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
     }
 }
 
-int g_attn_vit = 1;                    // 0 = off (attn_fullrow), 1 = 12-wave kernel, 2 = 16-wave kernel where n == 257
+// 0 = off (attn_fullrow), 1 = 12-wave kernel; where n == 257: 2 = 16-wave kernel, 3 = + 16-byte output stores (default), 4 = + normalisation
+// behind PV.  Measured at B = 128 (profiles/r03_call5_attention_modes.log): 159.2 / 159.1 / 152.2 / 137.5 us for 1 / 2 / 3 / 4; end to end
+// 121.9 / - / 121.5 / 121.0 ms per 256 images.  4 moves a rounding point away from the reference's (the normalised probabilities are no
+// longer what is rounded to half): its outputs sit ~0.8 bf16 ulp (rms) from the other kernels', at the same distance from fp32 - left
+// selectable, not the default.
+int g_attn_vit = 3;
 #ifdef SEEDMI_DEVTOOLS
 unsigned long long* g_attn_dbg = nullptr;
 #endif

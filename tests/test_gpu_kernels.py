@@ -506,7 +506,7 @@ def ref_attention(q, k, v, heads, scale, causal, round_s=True):
 def test_attention_fullrow(lib, B, H, hd, nq, nk, causal, trv):
     if trv >= 3 and not (nq == nk == 257 and hd == 88 and not causal):
         pytest.skip("the 16-wave kernel serves the 257-token ViT shape only (other shapes take the same kernels as vit_pipeline)")
-    default_vit = 1
+    default_vit = 3
     L.check(lib.seedmi_set_option(b"attn_vit", {5: 4, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "set_option")
     L.check(lib.seedmi_set_option(b"attn_trv", min(trv, 1)), "set_option")
     gen = torch.Generator().manual_seed(B * 100 + nk)

@@ -31,4 +31,4 @@ for trv in (5, 4, 3, 2, 1):                               # 5 / 4 / 3 = 16-wave 
     med = sorted(ts)[len(ts) // 2]
     print(f"trv={trv}: {med * 1e3:.1f} us  {flops / med / 1e9:.1f} TFLOP/s", flush=True)
 lib.seedmi_set_option(b"attn_trv", 1)
-lib.seedmi_set_option(b"attn_vit", 1)
+lib.seedmi_set_option(b"attn_vit", 3)

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seed_amd import lib as L  # noqa: E402
 
 lib = L.load()
+lib.seedmi_set_option(b"attn_vit", 1)                      # (the stamps live in the 12-wave kernel)
 lib.seedmi_attn_vit_timing.restype = ctypes.c_int
 lib.seedmi_attn_vit_timing.argtypes = [ctypes.c_void_p]
 B, H, hd, n = int(os.environ.get("B", "128")), 16, 88, 257
