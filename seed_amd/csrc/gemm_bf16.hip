@@ -185,9 +185,11 @@ SEEDMI_DEVINL void fold_accumulators(f32x4 (&acc)[8][4], const FoldLds& fold) {
 // after_loads: called once, after the epilogue's up-front loads have been issued AND waited for and before its first store (the
 // persistent kernel starts the next tile's LDS-DMA there: hipcc waits vmcnt(0) for every ordinary load while LDS-DMA is in flight,
 // so DMA issued ahead of the bias / residual loads puts its own latency into the epilogue's critical path)
+// row_end: rows >= row_end are computed but not stored (the 256x256 kernel's re-divided ragged tiles own 64 of the 128 rows); < 0 = p.M
 template <int EPI, int MT, bool LANE4 = true, typename Hook = NoHook, bool LNF = false>
 SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int mrow0, int nb, int li, const char* lut = nullptr,
-                                 Hook after_loads = Hook()) {
+                                 Hook after_loads = Hook(), int row_end = -1) {
+    const int Mend = row_end < 0 ? p.M : row_end;
     const int span0 = nb & ~63;                                   // first column of the wave's 64-column span (wave-uniform)
     // (the LayerNorm-fold variants require N % 64 == 0: a wave's span is inside N or outside it as a whole, no ragged code)
     const bool span_full = LANE4 && EPI != EPI_SWIGLU && (LNF || span0 + 64 <= p.N) && p.skip_epilogue == 0;
@@ -276,7 +278,7 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
         const int m = mrow0 + 16 * mi + li;
-        if (!span_full && m >= p.M) continue;                     // (the transposing path keeps every lane of the row alive)
+        if (!span_full && m >= Mend) continue;                    // (the transposing path keeps every lane of the row alive)
         float v[16];
         if (CONSUME) {
 #pragma unroll
@@ -347,7 +349,7 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             uint32_t spk[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) spk[i] = pack2bf(v[2 * i], v[2 * i + 1]);
-            store_row_stats(p, row_stats(spk, 16), m, nb);
+            if (m < Mend) store_row_stats(p, row_stats(spk, 16), m, nb);
         }
         if (EPI == EPI_SWIGLU) {
             // interleaved rows: even = gate_proj, odd = up_proj  ->  out[m][n/2] = silu(gate) * up
@@ -386,7 +388,7 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                         a[d] = t2[0];
                         c[d] = t2[1];
                     }
-                    if (m < p.M) {
+                    if (m < Mend) {
                         bf16_t* wp = p.C + ((uint32_t)out_row * (uint32_t)p.ldc + wcol);
                         __builtin_nontemporal_store((u32x4_t){a[0], a[1], a[2], a[3]}, (u32x4_t*)wp);
                         __builtin_nontemporal_store((u32x4_t){c[0], c[1], c[2], c[3]}, (u32x4_t*)(wp + 32));
@@ -424,7 +426,8 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
 // load of the epilogue precedes every store, nothing spills.
 template <bool STATS, typename Hook, bool EARLY = false>
 SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li, Hook after_loads,
-                                           char* stat_lds) {
+                                           char* stat_lds, int row_end = -1) {
+    const int Mend = row_end < 0 ? p.M : row_end;
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     const uint32_t wcol = (uint32_t)((nb & ~63) + 8 * ((nb >> 4) & 3));
     float bias[16];
@@ -489,7 +492,7 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
     };
     auto store_row = [&](int mi_abs, const u32x4_t& oa, const u32x4_t& oc) {
         const int m = mrow0 + 16 * mi_abs + li;
-        if (m < p.M) {
+        if (m < Mend) {
             bf16_t* wp = p.C + ((uint32_t)m * (uint32_t)p.ldc + wcol);
             if (p.residual_nt) {
                 __builtin_nontemporal_store(oa, (u32x4_t*)wp);
@@ -548,7 +551,7 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
         for (int j = 0; j < 2; ++j) {
             const int m = mrow0 + 64 * j + lane;
             const float2 st = *(const float2*)(stat_lds + 8 * (64 * j + lane));
-            if (m < p.M) *(float2*)(p.stats_out + ((size_t)(nb >> 6) * p.stats_ld + m) * 2) = st;
+            if (m < Mend) *(float2*)(p.stats_out + ((size_t)(nb >> 6) * p.stats_ld + m) * 2) = st;
         }
     }
 }
@@ -560,8 +563,10 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
 // has the whole of that work to land in; then the hook waits for it (vmcnt retires in order: waiting AFTER the stores would also wait
 // for the stores, which is what the tile's opening wait used to do), and only then the tile's 16 stores go out.
 template <int EPI, typename Hook>
-SEEDMI_DEVINL void gemm_epilogue_fold8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li, const char* lut, Hook after_loads) {
+SEEDMI_DEVINL void gemm_epilogue_fold8(const GemmParams& p, f32x4 (&acc)[8][4], int mrow0, int nb, int li, const char* lut, Hook after_loads,
+                                       int row_end = -1) {
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const int Mend = row_end < 0 ? p.M : row_end;
     if (nb >= p.N) {
         after_loads();
         return;
@@ -603,7 +608,7 @@ SEEDMI_DEVINL void gemm_epilogue_fold8(const GemmParams& p, f32x4 (&acc)[8][4], 
     };
     auto store_row = [&](int mi, const u32x4_t& oa, const u32x4_t& oc) {
         const int m = mrow0 + 16 * mi + li;
-        if (m < p.M) {
+        if (m < Mend) {
             bf16_t* wp = p.C + ((uint32_t)m * (uint32_t)p.ldc + wcol);
             __builtin_nontemporal_store(oa, (u32x4_t*)wp);
             __builtin_nontemporal_store(oc, (u32x4_t*)(wp + 32));
@@ -806,6 +811,13 @@ SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid
 //   bit 4: residual epilogue: the second half's residual rows are requested after TWO rows of the first half are finished (their
 //          registers are free by then) instead of after four, so that their HBM round trip runs under the other two rows' arithmetic.
 //   bit 5: the second-dispatched wave group (waves 4..7) runs at s_setprio 1 throughout (the CDNA guide's static form of T5).
+//   bit 7: ragged last n-tile re-divided.  N = 1408 (proj, fc2) is 5.5 n-tiles, N = 4224 (qkv) 16.5: in the last one only the column groups
+//          wn = 0, 1 have columns and the waves wn = 2, 3 stand by (8.3 % / 3 % of those GEMMs' MFMA time spent on a half-empty tile).
+//          Where the tile has <= 128 valid columns every wave takes 64 rows x 64 columns instead: wave (wm, wn) computes rows
+//          128 wm + 64 (wn >> 1) .. + 63 of columns 64 (wn & 1) .. + 63, i.e. phases P1 / P2 on its own A rows and the W fragments of column
+//          group wn & 1, nothing in P3 / P4 (same requests, waits and barriers).  The K loop of such a tile is its own instantiation of the
+//          K-tile body (no branch in the ordinary one); the epilogue is the ordinary one, told to keep rows below mrow0 + 64 only - no
+//          second epilogue instantiation (what made round 2's three attempts spill).  Each element's K chain is unchanged: bit-identical.
 //   bit 6: TWO phases of 32 MFMAs per K-tile instead of four of 16 (not combined with bits 1-3).  The phase stamps of the four-phase loop
 //          (tools/gemm_phase_times.py, profiles/r03_call2_*.log) show every phase costing the partner's MFMA section (300-330 cycles for 16
 //          MFMAs) plus ~90 cycles of hand-over (barrier release + the fragment reads' tail): 8 x ~400 = 3200 cycles per K-tile against 2048
@@ -820,7 +832,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr bool PRIO = SEEDMI_GEMM_PRIO;
     constexpr bool PREWAIT = (SCHED & 1) != 0, WPRE = (SCHED & 2) != 0, ASPLIT = (SCHED & 4) != 0, WSPLIT = (SCHED & 8) != 0;
     constexpr bool RES_EARLY = (SCHED & 16) != 0, STATIC_PRIO = (SCHED & 32) != 0, TWOPH = (SCHED & 64) != 0;
+    // bit 8: the same re-division as bit 7, but ONE K-tile body for every tile with wave-uniform branches around the P3 reads / MFMAs and
+    // the P4 MFMAs (two separate K loops made hipcc spill ~125 registers per lane into both of them)
+    constexpr bool RAGBR = (SCHED & 256) != 0;
+    constexpr bool RAGSPLIT = (SCHED & 128) != 0 || RAGBR;
+    bool tile_ragged = false;
     static_assert(!TWOPH || (SCHED & 14) == 0, "the two-phase schedule has its own request placement");
+    static_assert(!(TWOPH && RAGSPLIT), "the ragged-tile split lives in the four-phase K-tile body");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -898,6 +916,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int rowW0 = 64 * wn + 16 * (li >> 2) + (li & 3);
     const int rdA0 = wm * HALF_BYTES + li * 128 + ((g ^ swzA(li)) << 4);
     const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((g ^ swzW(rowW0)) << 4);
+    // (RAGSPLIT: the bases are formed per tile, from a lane id taken there - tile_rdA / tile_rdW below - so that neither K loop's address
+    // arithmetic is hoisted over the whole kernel next to the other's)
+    int tile_rdA = rdA0, tile_rdW = rdW0;
 
     f32x4 acc[8][4];
     auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
@@ -1009,12 +1030,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
     // ---- one K-tile, four phases.  fx holds / receives W(nh0), fy W(nh1).  WPRE: on entry fx already holds this K-tile's W(nh0) (read in the
     //      previous K-tile's P4 or ahead of the loop); in P4 fy - dead after P3 - receives W(nh0) of K-tile kt + 1, so the caller swaps roles.
-    auto ktile = [&](const int kt, const int ke, bf16x8 (&fx)[4], bf16x8 (&fy)[4], const bool stamp) {
+    auto ktile = [&](auto rg_tag, const int kt, const int ke, bf16x8 (&fx)[4], bf16x8 (&fy)[4], const bool stamp) {
+        constexpr bool RGT = decltype(rg_tag)::value;   // ragged-tile split: this wave's 64 rows x 64 columns, phases P1 / P2 only
+        const bool RG = RGT || (RAGBR && tile_ragged);  // (RAGBR: decided per tile at run time)
         const char* sb = smem + (kt & 1) * KT_BYTES;
-        const char* pa0 = sb + rdA0;                    // k-step 0
-        const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
-        const char* pw0 = sb + rdW0;
-        const char* pw1 = sb + (rdW0 ^ 64);
+        const int bA = RAGSPLIT ? tile_rdA : rdA0, bW = RAGSPLIT ? tile_rdW : rdW0;
+        const char* pa0 = sb + bA;                      // k-step 0
+        const char* pa1 = sb + (bA ^ 64);               // k-step 1
+        const char* pw0 = sb + bW;
+        const char* pw1 = sb + (bW ^ 64);
         (void)stamp;
         if (stamp) GSTAMP(16);
 
@@ -1098,8 +1122,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         if (stamp) GSTAMP(7);
 
         // ================= P3: (mh1, nh1) =================
+        if (!RG) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
+            for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
+        }
         // WPRE: W(kt+1) - requested in P4 of kt-1 (or by the prologue), i.e. older than the four A(kt+1) requests of this K-tile - must be
         // complete one phase before P4 reads it
         if (WPRE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1111,6 +1137,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         SEEDMI_SCHED_FENCE();
         if (stamp) GSTAMP(9);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (!RG) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1118,6 +1145,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
+        }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
         if (stamp) GSTAMP(10);
@@ -1140,8 +1168,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
         if (WPRE && kt + 1 < ke) {                     // next K-tile's W(nh0): other parity, retired by P3's counted wait + two barriers
             const char* sn = smem + ((kt + 1) & 1) * KT_BYTES;
-            const char* qw0 = sn + rdW0;
-            const char* qw1 = sn + (rdW0 ^ 64);
+            const char* qw0 = sn + bW;
+            const char* qw1 = sn + (bW ^ 64);
 #pragma unroll
             for (int t = 0; t < 2; ++t) { fy[t] = *(const bf16x8*)(qw0 + t * 512); fy[2 + t] = *(const bf16x8*)(qw1 + t * 512); }
         }
@@ -1151,6 +1179,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         SEEDMI_SCHED_FENCE();
         if (stamp) GSTAMP(13);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (!RG) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1158,6 +1187,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
+        }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
         if (stamp) GSTAMP(14);
@@ -1339,7 +1369,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // compute.  It walks the same barriers and issues its share of the LDS-DMA, but reads no fragments and issues no MFMA: the tile's
     // live waves keep the LDS bandwidth and the power budget to themselves (proj -2 %, fc2 -2.9 % at B = 256).
     const bool live = (en0 + 64 * wn) < p.N;
-    if (live && TWOPH) {
+    // ragged split (SCHED bit 7): every wave computes in a tile with <= 128 valid columns (not with statistics by tile: their combine
+    // assumes the ordinary wave -> row map)
+    const bool ragged = RAGSPLIT && (p.N - en0) <= 128 && !p.stats_by_tile;
+    using rg_no = std::false_type;
+    using rg_yes = std::true_type;
+    if (RAGSPLIT) {
+        // this tile's fragment read bases: ordinary = A rows 16 mi + li of half-tile wm, W rows of column group wn; ragged split = A rows
+        // 64 (wn >> 1) + 16 mi + li, W rows of column group wn & 1 (W half-tile 0)
+        const int kl = fresh_lane(), kli = kl & 15, kg = kl >> 4;
+        const int wcol = ragged ? (wn & 1) : wn;
+        const int rw = 64 * wcol + 16 * (kli >> 2) + (kli & 3);
+        tile_rdW = 2 * HALF_BYTES + (wcol >> 1) * HALF_BYTES + (rw & 127) * 128 + ((kg ^ swzW(rw)) << 4);
+        tile_rdA = wm * HALF_BYTES + (ragged ? (wn >> 1) * (64 * 128) : 0) + kli * 128 + ((kg ^ swzA(kli)) << 4);
+    }
+    tile_ragged = ragged;
+    if (ragged && !RAGBR) {
+        if (WPRE) {
+            const char* sb = smem + (kb & 1) * KT_BYTES;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(sb + tile_rdW + t * 512); fw0[2 + t] = *(const bf16x8*)(sb + (tile_rdW ^ 64) + t * 512); }
+            int kt = kb;
+            for (; kt + 1 < ke; kt += 2) {
+                ktile(rg_yes(), kt, ke, fw0, fw1, false);
+                ktile(rg_yes(), kt + 1, ke, fw1, fw0, false);
+            }
+            if (kt < ke) ktile(rg_yes(), kt, ke, fw0, fw1, false);
+        } else {
+            for (int kt = kb; kt < ke; ++kt) ktile(rg_yes(), kt, ke, fw0, fw1, false);
+        }
+    } else if ((live || ragged) && TWOPH) {
         for (int kt = kb; kt < ke; ++kt) ktile2(kt, kb, ke);
     } else if (!live && TWOPH) {
         // same requests, waits and barriers as ktile2, no fragment reads, no MFMA
@@ -1361,22 +1420,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
         }
-    } else if (live) {
+    } else if (live || ragged) {
         if (WPRE) {
             // W(nh0) of the segment's first K-tile (every later one is read in the P4 in front of it); the two fragment sets swap roles per K-tile
             const char* sb = smem + (kb & 1) * KT_BYTES;
+            const int bW = RAGSPLIT ? tile_rdW : rdW0;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(sb + rdW0 + t * 512); fw0[2 + t] = *(const bf16x8*)(sb + (rdW0 ^ 64) + t * 512); }
+            for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(sb + bW + t * 512); fw0[2 + t] = *(const bf16x8*)(sb + (bW ^ 64) + t * 512); }
             int kt = kb;
             for (; kt + 1 < ke; kt += 2) {
-                ktile(kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
-                ktile(kt + 1, ke, fw1, fw0, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
+                ktile(rg_no(), kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
+                ktile(rg_no(), kt + 1, ke, fw1, fw0, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
             }
-#if !defined(SEEDMI_EXP) || SEEDMI_EXP != 1
-            if (kt < ke) ktile(kt, ke, fw0, fw1, false);
-#endif
+            if (kt < ke) ktile(rg_no(), kt, ke, fw0, fw1, false);
         } else {
-            for (int kt = kb; kt < ke; ++kt) ktile(kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
+            for (int kt = kb; kt < ke; ++kt) ktile(rg_no(), kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
         }
     } else {
         for (int kt = kb; kt < ke; ++kt) {
@@ -1405,8 +1463,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // the epilogue it cost 110-290 B of scratch per lane, reloaded behind the tile's stores)
         FoldLds fold;
         const int ln = SCHED != 0 ? fresh_lane() : lane;
-        fold.cs = smem + STAT_OFF + fold_cur * FOLD_SET_BYTES + 4 * (64 * wn + 16 * (ln >> 4));
-        fold.st = smem + STAT_OFF + ((p.ln_planes > 0 || fold_cur == 0) ? FOLD_FIN_OFF : FOLD_X_OFF) + 8 * (128 * wm + (ln & 15));
+        fold.cs = smem + STAT_OFF + fold_cur * FOLD_SET_BYTES + 4 * (64 * (ragged ? (wn & 1) : wn) + 16 * (ln >> 4));
+        fold.st = smem + STAT_OFF + ((p.ln_planes > 0 || fold_cur == 0) ? FOLD_FIN_OFF : FOLD_X_OFF) +
+                  8 * (128 * wm + (ragged ? 64 * (wn >> 1) : 0) + (ln & 15));
         fold_accumulators(acc, fold);
         SEEDMI_SCHED_FENCE();
     }
@@ -1456,13 +1515,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     } else {
         const int eln = SCHED != 0 ? fresh_lane() : lane;
         const int eli = eln & 15;
-        const int enb = en0 + 64 * wn + 16 * (eln >> 4);
+        // (ragged split: the wave's accumulators 0..3 are rows 64 (wn >> 1) .. + 63 of column group wn & 1; row groups 4..7 hold nothing)
+        const int enb = en0 + 64 * (ragged ? (wn & 1) : wn) + 16 * (eln >> 4);
+        const int emrow0 = em0 + 128 * wm + (ragged ? 64 * (wn >> 1) : 0);
+        const int erow_end = ragged ? min(p.M, emrow0 + 64) : -1;
         if (EPI == EPI_BIAS_RESIDUAL && p.skip_epilogue == 0 && (enb & ~63) + 64 <= p.N) {
-            gemm_epilogue_residual8<LNF, decltype(hook), RES_EARLY>(p, acc, em0 + 128 * wm, enb, eli, hook, smem + STAT_OFF + wave * 1024);
+            gemm_epilogue_residual8<LNF, decltype(hook), RES_EARLY>(p, acc, emrow0, enb, eli, hook, smem + STAT_OFF + wave * 1024, erow_end);
         } else if (PREWAIT && FOLD_IN && p.skip_epilogue == 0) {
-            gemm_epilogue_fold8<EPI>(p, acc, em0 + 128 * wm, enb, eli, lut, hook);
+            gemm_epilogue_fold8<EPI>(p, acc, emrow0, enb, eli, lut, hook, erow_end);
         } else if (p.skip_epilogue != 1) {
-            gemm_epilogue<EPI, 8, true, decltype(hook), LNF>(p, acc, em0 + 128 * wm, enb, eli, lut, hook);
+            gemm_epilogue<EPI, 8, true, decltype(hook), LNF>(p, acc, emrow0, enb, eli, lut, hook, erow_end);
         } else {
             hook();
             if (acc[0][0][0] == 123.456f) p.C[0] = 0;       // keep the accumulators alive
@@ -1555,6 +1617,7 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
             case SEEDMI_SCHED_ONLY: return launch_gemm256_sched<EPI, LNF, SEEDMI_SCHED_ONLY>(p, stream, sk_ws, sk_ws_bytes);
 #else
             case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);
+            case 287: return launch_gemm256_sched<EPI, LNF, 287>(p, stream, sk_ws, sk_ws_bytes);
 #ifdef SEEDMI_DEVTOOLS                                 // measured steps and the rejected two-phase schedule (tools/gemm_sched_ab.py)
             case 7: return launch_gemm256_sched<EPI, LNF, 7>(p, stream, sk_ws, sk_ws_bytes);
             case 15: return launch_gemm256_sched<EPI, LNF, 15>(p, stream, sk_ws, sk_ws_bytes);
@@ -1625,7 +1688,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 127) {      // (-1 = the default; values without a compiled variant run schedule 0)
+    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 511) {      // (-1 = the default; values without a compiled variant run schedule 0)
         if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
         return SEEDMI_OK;

@@ -9,8 +9,9 @@ for l in open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/kt_compact.csv")
     ev.append((n, q, s, int(a), int(b)))
 ev.sort(key=lambda e: e[3])
 im = [i for i, e in enumerate(ev) if "im2col" in e[0]]
-vq = [i for i, e in enumerate(ev) if "vq_argmin" in e[0]]
-nparts = 2
+vq = [i for i, e in enumerate(ev) if "argmin" in e[0]]           # vq_argmin_kernel / vq_head_argmin_kernel: the last kernel of a sub-batch
+import os
+nparts = int(os.environ.get("NPARTS", "2"))
 t0 = ev[im[-nparts]][3]
 t1 = max(ev[i][4] for i in vq[-nparts:])
 seg = [e for e in ev if e[3] >= t0 and e[4] <= t1]
