@@ -378,14 +378,23 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
     stage(p.Q, p.ldq, Qsm, item);
     stage(p.V, p.ldv, Vsm, item, FLASH);
     const float L2E = 1.4426950408889634f;
+#ifdef SEEDMI_DEVTOOLS
+    // phase clock stamps of workgroup 0 (tools/attn_phase_times.py): s_memtime into SGPR pairs, read back only at the item's end
+    unsigned long long vt[9];
+#define V16STAMP(k_) do { if (p.dbg && blockIdx.x == 0) asm volatile("s_memtime %0" : "=s"(vt[k_])); } while (0)
+#else
+#define V16STAMP(k_) do {} while (0)
+#endif
 
     for (int it = 0;; ++it) {
         const int b = item / p.heads, h = item - b * p.heads;
         const int side_a = it & 15, side_b = (it + 6) & 15;           // waves that take row 256: scores + softmax / PV (different SIMDs)
+        V16STAMP(0);
         // ---- K(item), Q(item) landed everywhere (only this wave's V pieces may still be in flight)
         wait_vm(my_pieces);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        V16STAMP(1);
 
         // ---- S^T = K Q^T for query tile `wave`, softmax, P packed to bf16 MFMA operands
         bf16x8 pf[VKK];
@@ -420,6 +429,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                 for (int ks = 0; ks < 3; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kt & 1][ks], qf[ks], s[kt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);         // (keeps the fragment reads one tile ahead, not ten: 128 registers per wave)
             }
+            V16STAMP(2);
             // softmax over keys {16 kt + 4 g + r}: S rounded to half like the reference's matmul output.  Four running maxima keep the
             // dependent chain short (max is exact in any order).
             float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -492,6 +502,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        V16STAMP(3);
         if (wave == side_a) {
             // ---- row 256 (query tile 16, rows 257..271 of the Q image are zero): operands swapped, S[q = 4 g + r][key = 16 kt + li].
             //      Only q == 0 exists: lanes 0..15, accumulator register 0.
@@ -553,10 +564,12 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        V16STAMP(4);
         // ---- V(item) landed; every wave is done with K(item) and Q(item); the side row is in LDS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        V16STAMP(5);
         const int next = item + gridDim.x;
         const bool more = next < p.items;
         if (more) {
@@ -630,8 +643,10 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            V16STAMP(6);
             store_o(o, wave, false);
         }
+        V16STAMP(7);
         if (wave == side_b) {
             // row 256: P^T operand straight from the side row (lane group g takes keys 32 kk + 4 g .. + 3 and + 16 .. : every column of
             // the operand is the same row, only column li == 0 is stored)
@@ -658,6 +673,15 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
             }
             store_o(o, 16, true);
         }
+        V16STAMP(8);
+#ifdef SEEDMI_DEVTOOLS
+        if (p.dbg && blockIdx.x == 0 && it < 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (fresh_lane() == 0)
+                for (int q = 0; q < 9; ++q) p.dbg[(wave * 8 + it) * 9 + q] = vt[q];
+        }
+#endif
         if (!more) break;
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -673,13 +697,15 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
 // longer what is rounded to half): its outputs sit ~0.8 bf16 ulp (rms) from the other kernels', at the same distance from fp32 - left
 // selectable, not the default.
 int g_attn_vit = 3;
+#undef V16STAMP
 #ifdef SEEDMI_DEVTOOLS
 unsigned long long* g_attn_dbg = nullptr;
 #endif
 
 }  // namespace
 #ifdef SEEDMI_DEVTOOLS
-// devtools: device buffer of 12 x 8 x 6 uint64 that workgroup 0 of the next ViT attention launches fills with phase clock stamps
+// devtools: device buffer (>= 16 x 8 x 9 uint64) that workgroup 0 of the next ViT attention launches fills with phase clock stamps
+// (12-wave kernel: [wave][item][6]; 16-wave kernel: [wave][item][9])
 extern "C" int seedmi_attn_vit_timing(void* buf) { g_attn_dbg = (unsigned long long*)buf; return SEEDMI_OK; }
 #endif
 
