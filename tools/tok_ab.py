@@ -49,7 +49,7 @@ for r in range(ROUNDS + 1):
         # option sets that only choose between kernels computing the same thing must give identical ids; the LayerNorm fold moves a
         # rounding point, so its two settings are only compared within themselves
         # (tile statistics associate the row sums differently, attn_vit=4 moves the softmax normalisation behind PV: own groups)
-        key = ("tokenize_lnfold=0" in s, "tokenize_tile_stats=1" in s, "attn_vit=4" in s)
+        key = ("tokenize_lnfold=0" in s, "tokenize_tile_stats=1" in s, "attn_vit=4" in s or "attn_vit=6" in s)
         if ref.get(key) is None:
             ref[key] = ids.clone()
         same = (ids == ref[key]).float().mean().item()
