@@ -691,354 +691,13 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
     }
 }
 
-// ======================================================================================================
-// 8-wave form for n == 257: TWO query tiles per wave (tiles w and w + 8), both fed by the SAME K and V fragments.
-//
-// Phase stamps of the 16-wave kernel (tools/attn16_phase_times.py, profiles/r03_call8_attention_phase_stamps.log): the item's two MFMA
-// phases are bound by LDS fragment reads, not by the matrix pipe - every wave reads all of K (51 ds_read_b128) and all of V (108
-// ds_read_b64_tr_b16) for ONE 16-query tile, sixteen times per item: PV takes 5.3 k cycles for the first wave of a SIMD and 10.4 k for the
-// last against 0.86 k of MFMA issue per wave.  Here a fragment read feeds two tiles' MFMAs (half the LDS reads per item, two independent
-// accumulator chains per fragment), eight waves of 256 registers each hold both tiles' scores (136 registers), and the softmax - per tile
-// the same instruction stream as before - runs on two waves per SIMD instead of four.  Row 256 and everything else as in the 16-wave
-// kernel (same arithmetic, rounding points and summation order: rows 0..255 are bit-identical to it).
-constexpr int V8_WAVES = 8;
-
-SEEDMI_DEVINL void wait_vm8(int leave) {                // (up to 7 of this wave's LDS-DMA pieces stay in flight)
-    if (leave >= 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else wait_vm(leave);
-}
-
-template <bool ROUND_S, bool FLASH>
-__global__ __launch_bounds__(64 * V8_WAVES) void attn_vit8_kernel(VitAttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* Ksm = (bf16_t*)smem;
-    bf16_t* Qsm = (bf16_t*)(smem + VKQ_BYTES);
-    bf16_t* Vsm = (bf16_t*)(smem + 2 * VKQ_BYTES);
-    bf16_t* Psm = (bf16_t*)(smem + V16_P_OFF);
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int n = V16_N;
-    constexpr int total_chunks = n * VCHL;
-    constexpr int npieces = (total_chunks + 63) >> 6;                 // 49 pieces of 1 KiB per matrix
-    const int my_pieces = (npieces - wave + V8_WAVES - 1) / V8_WAVES;     // 7 for wave 0, 6 for the others
-
-    for (int i = tid; i < V16_LDS_BYTES / 16; i += 64 * V8_WAVES) *(uint4*)(smem + 16 * i) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    if (FLASH) {
-        for (int r = tid; r < VNKP; r += 64 * V8_WAVES)
-            *(uint4*)((char*)Vsm + r * (VLD * 2) + 16 * ((VCHL - 1) ^ vswz(r))) = make_uint4(0x3f80u, 0, 0, 0);
-        __syncthreads();
-    }
-
-    auto stage = [&](const bf16_t* base, int ld, bf16_t* dst, int item, bool skip_pad = false) {
-        const int b = item / p.heads, h = item - b * p.heads;
-        const bf16_t* src = base + (size_t)b * n * ld + h * VHD;
-        const int lane = fresh_lane();
-        for (int j = 0; j < my_pieces; ++j) {
-            const int piece = wave + V8_WAVES * j;
-            const int q0 = 64 * piece + lane;
-            const int q = min(q0, total_chunks - 1);
-            const int row = q / VCHL;
-            const int c0 = (q - row * VCHL) ^ vswz(row);
-            const int c = min(c0, VCH - 1);
-            if (!skip_pad || (c0 < VCH && q0 < total_chunks)) glds16v(src + (size_t)row * ld + 8 * c, (char*)dst + piece * 1024);
-        }
-    };
-
-    int item = blockIdx.x;
-    if (item >= p.items) return;
-    stage(p.K, p.ldk, Ksm, item);
-    stage(p.Q, p.ldq, Qsm, item);
-    stage(p.V, p.ldv, Vsm, item, FLASH);
-    const float L2E = 1.4426950408889634f;
-
-    for (int it = 0;; ++it) {
-        const int b = item / p.heads, h = item - b * p.heads;
-        const int side_a = it & 7, side_b = (it + 3) & 7;             // waves that take row 256: scores + softmax / PV (different SIMDs)
-        wait_vm8(my_pieces);                                          // K(item), Q(item) landed (this wave's V pieces may still fly)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-
-        bf16x8 pf[2][VKK];
-        {
-            const int lane = fresh_lane(), li = lane & 15, g = lane >> 4;
-            int koff[3];
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) koff[ks] = li * (VLD * 2) + 16 * ((4 * ks + g) ^ vswz(li));
-            bf16x8 qf[2][3];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {            // q * scale rounded to half; the 12th chunk (cols 88..95) is zero
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (32 * ks + 8 * g < VHD) v = *(const uint4*)((const char*)Qsm + 16 * (wave + 8 * u) * (VLD * 2) + koff[ks]);
-                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) w[i] = pack2bf(lo_bf(w[i]) * p.scale, hi_bf(w[i]) * p.scale);
-                    qf[u][ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-                }
-            f32x4 s[2][VNT];
-            bf16x8 fk[2][3];                                 // K fragments of one key tile, double buffered; each feeds both query tiles
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) fk[0][ks] = *(const bf16x8*)((const char*)Ksm + koff[ks]);
-#pragma unroll
-            for (int kt = 0; kt < VNT; ++kt) {
-                if (kt + 1 < VNT) {
-#pragma unroll
-                    for (int ks = 0; ks < 3; ++ks) fk[(kt + 1) & 1][ks] = *(const bf16x8*)((const char*)Ksm + (kt + 1) * 16 * (VLD * 2) + koff[ks]);
-                }
-                s[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                s[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    s[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kt & 1][ks], qf[0][ks], s[0][kt], 0, 0, 0);
-                    s[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kt & 1][ks], qf[1][ks], s[1][kt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                // softmax of tile u over keys {16 kt + 4 g + r}: S rounded to half like the reference's matmul output
-                float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-                for (int kt = 0; kt < VNT; ++kt) {
-                    float v0 = s[u][kt][0], v1 = s[u][kt][1], v2 = s[u][kt][2], v3 = s[u][kt][3];
-                    if (ROUND_S) {
-                        const uint32_t w0 = pack2bf(v0, v1), w1 = pack2bf(v2, v3);
-                        v0 = lo_bf(w0); v1 = hi_bf(w0); v2 = lo_bf(w1); v3 = hi_bf(w1);
-                    }
-                    if (kt == VNT - 1) {                     // keys 256 .. 271: only key 256 (g == 0, r == 0) exists
-                        v0 = (g == 0) ? v0 : -INFINITY;
-                        v1 = v2 = v3 = -INFINITY;
-                    }
-                    s[u][kt][0] = v0; s[u][kt][1] = v1; s[u][kt][2] = v2; s[u][kt][3] = v3;
-                    mx4[kt & 3] = fmaxf(mx4[kt & 3], fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
-                }
-                float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float nmx = -mx * L2E;
-                const f32x2 l2 = {L2E, L2E}, nm2 = {nmx, nmx};
-                if (FLASH) {
-#pragma unroll
-                    for (int kk = 0; kk < VKK; ++kk) {
-                        uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2) {
-                            const int kt = 2 * kk + h2;
-                            if (kt < VNT) {
-                                const f32x2 a0 = __builtin_elementwise_fma((f32x2){s[u][kt][0], s[u][kt][1]}, l2, nm2);
-                                const f32x2 a1 = __builtin_elementwise_fma((f32x2){s[u][kt][2], s[u][kt][3]}, l2, nm2);
-                                w[2 * h2] = pack2bf(__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1]));
-                                w[2 * h2 + 1] = pack2bf(__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1]));
-                            }
-                        }
-                        pf[u][kk] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-                    }
-                } else {
-                    float sum = 0.f;                         // (one chain in (kt, r) order, like the other ViT kernels: bit-identical rows)
-#pragma unroll
-                    for (int kt = 0; kt < VNT; ++kt) {
-                        const f32x2 a0 = __builtin_elementwise_fma((f32x2){s[u][kt][0], s[u][kt][1]}, l2, nm2);
-                        const f32x2 a1 = __builtin_elementwise_fma((f32x2){s[u][kt][2], s[u][kt][3]}, l2, nm2);
-                        const float arg[4] = {a0[0], a0[1], a1[0], a1[1]};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float e = __builtin_amdgcn_exp2f(arg[r]);
-                            s[u][kt][r] = e;
-                            sum += e;
-                        }
-                    }
-                    sum += __shfl_xor(sum, 16, 64);
-                    sum += __shfl_xor(sum, 32, 64);
-                    const float inv = __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-                    for (int kk = 0; kk < VKK; ++kk) {
-                        uint4 pw;
-                        pw.x = pack2bf(s[u][2 * kk][0] * inv, s[u][2 * kk][1] * inv);
-                        pw.y = pack2bf(s[u][2 * kk][2] * inv, s[u][2 * kk][3] * inv);
-                        pw.z = pw.w = 0u;                          // (keys 272..287 do not exist: P = 0)
-                        if (2 * kk + 1 < VNT) {
-                            pw.z = pack2bf(s[u][2 * kk + 1][0] * inv, s[u][2 * kk + 1][1] * inv);
-                            pw.w = pack2bf(s[u][2 * kk + 1][2] * inv, s[u][2 * kk + 1][3] * inv);
-                        }
-                        pf[u][kk] = __builtin_bit_cast(bf16x8, pw);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (wave == side_a) {
-            // ---- row 256: operands swapped, S[q = 4 g + r][key = 16 kt + li]; only q == 0 exists (lanes 0..15, register 0)
-            const int lane = fresh_lane(), li = lane & 15, g = lane >> 4;
-            int koff[3];
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) koff[ks] = li * (VLD * 2) + 16 * ((4 * ks + g) ^ vswz(li));
-            bf16x8 qf[3];
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (32 * ks + 8 * g < VHD) v = *(const uint4*)((const char*)Qsm + 16 * 16 * (VLD * 2) + koff[ks]);
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) w[i] = pack2bf(lo_bf(w[i]) * p.scale, hi_bf(w[i]) * p.scale);
-                qf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-            }
-            float t[VNT];
-            bf16x8 fk[2][3];
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) fk[0][ks] = *(const bf16x8*)((const char*)Ksm + koff[ks]);
-#pragma unroll
-            for (int kt = 0; kt < VNT; ++kt) {
-                if (kt + 1 < VNT) {
-#pragma unroll
-                    for (int ks = 0; ks < 3; ++ks) fk[(kt + 1) & 1][ks] = *(const bf16x8*)((const char*)Ksm + (kt + 1) * 16 * (VLD * 2) + koff[ks]);
-                }
-                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], fk[kt & 1][ks], a, 0, 0, 0);
-                float v = a[0];
-                if (ROUND_S) v = rbf(v);
-                if (kt == VNT - 1) v = (li == 0) ? v : -INFINITY;
-                t[kt] = v;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            float mx = t[0];
-#pragma unroll
-            for (int kt = 1; kt < VNT; ++kt) mx = fmaxf(mx, t[kt]);
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            const float nmx = -mx * L2E;
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < VNT; ++kt) {
-                t[kt] = __builtin_amdgcn_exp2f(fmaf(t[kt], L2E, nmx));
-                sum += t[kt];
-            }
-            float inv = 1.0f;
-            if (!FLASH) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-                inv = __builtin_amdgcn_rcpf(sum);
-            }
-            if (g == 0) {
-#pragma unroll
-                for (int kt = 0; kt < VNT; ++kt) Psm[16 * kt + li] = f2bf(t[kt] * inv);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        // ---- V(item) landed; every wave is done with K(item) and Q(item); the side row is in LDS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int next = item + gridDim.x;
-        const bool more = next < p.items;
-        if (more) {
-            stage(p.K, p.ldk, Ksm, next);
-            stage(p.Q, p.ldq, Qsm, next);
-        }
-
-        // ---- O^T = V^T P^T for both tiles from the same V fragments, store
-        const int lane = fresh_lane(), li = lane & 15, g = lane >> 4;
-        const bf16_t* vlane = Vsm + (4 * g + (li >> 2)) * VLD + 4 * (li & 1);
-        auto ldv = [&](bf16x8 (&f)[VHT], int kk) {
-#pragma unroll
-            for (int nn = 0; nn < VHT; ++nn) {
-                const bf16_t* vp = vlane + 32 * kk * VLD + 8 * ((2 * nn + ((li & 3) >> 1)) ^ vswz(4 * g));
-                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
-                const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 16 * VLD));
-                const uint2 lo = __builtin_bit_cast(uint2, a), hi = __builtin_bit_cast(uint2, c);
-                f[nn] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-            }
-        };
-        auto store_o = [&](const f32x4 (&o)[VHT], int qtile, bool first_row_only) {
-            const int sl = fresh_lane(), sg = sl >> 4;
-            float inv = 1.0f;
-            if (FLASH) inv = __builtin_amdgcn_rcpf(__shfl(o[VHT - 1][0], (sl & 15) + 32, 64));     // O^T row 88 = the row sum (lane group 2)
-            uint2 w[VHT];
-#pragma unroll
-            for (int nn = 0; nn < VHT; ++nn) {
-                w[nn].x = pack2bf(o[nn][0] * inv, o[nn][1] * inv);
-                w[nn].y = pack2bf(o[nn][2] * inv, o[nn][3] * inv);
-            }
-            bf16_t* op = p.O + ((size_t)b * n + 16 * qtile + (sl & 15)) * p.ldo + h * VHD;
-#pragma unroll
-            for (int nn = 0; nn < VHT; nn += 2) {           // 16-byte stores: see attn_vit16_kernel MODE bit 0
-                const auto tx = __builtin_amdgcn_permlane16_swap(w[nn].x, w[nn + 1].x, false, false);
-                const auto ty = __builtin_amdgcn_permlane16_swap(w[nn].y, w[nn + 1].y, false, false);
-                const int c0 = 16 * (nn + (sg & 1)) + 8 * (sg >> 1);
-                if (c0 + 8 <= VHD && !(first_row_only && (sl & 15) != 0)) *(uint4*)(op + c0) = make_uint4(tx[0], ty[0], tx[1], ty[1]);
-            }
-        };
-        {
-            f32x4 o[2][VHT];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int nn = 0; nn < VHT; ++nn) o[u][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            bf16x8 fv0[VHT], fv1[VHT];
-            ldv(fv0, 0);
-#pragma unroll
-            for (int kk = 0; kk < VKK; ++kk) {
-                if (kk & 1) {
-                    if (kk + 1 < VKK) ldv(fv0, kk + 1);
-#pragma unroll
-                    for (int nn = 0; nn < VHT; ++nn) {
-                        o[0][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pf[0][kk], o[0][nn], 0, 0, 0);
-                        o[1][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pf[1][kk], o[1][nn], 0, 0, 0);
-                    }
-                } else {
-                    if (kk + 1 < VKK) ldv(fv1, kk + 1);
-#pragma unroll
-                    for (int nn = 0; nn < VHT; ++nn) {
-                        o[0][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pf[0][kk], o[0][nn], 0, 0, 0);
-                        o[1][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pf[1][kk], o[1][nn], 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            store_o(o[0], wave, false);
-            store_o(o[1], wave + 8, false);
-        }
-        if (wave == side_b) {
-            f32x4 o[VHT];
-#pragma unroll
-            for (int nn = 0; nn < VHT; ++nn) o[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            bf16x8 fv0[VHT], fv1[VHT];
-            const bf16_t* prow = Psm + 4 * (fresh_lane() >> 4);
-            ldv(fv0, 0);
-#pragma unroll
-            for (int kk = 0; kk < VKK; ++kk) {
-                const uint2 plo = *(const uint2*)(prow + 32 * kk), phi = *(const uint2*)(prow + 32 * kk + 16);
-                const bf16x8 pr = __builtin_bit_cast(bf16x8, make_uint4(plo.x, plo.y, phi.x, phi.y));
-                if (kk & 1) {
-                    if (kk + 1 < VKK) ldv(fv0, kk + 1);
-#pragma unroll
-                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pr, o[nn], 0, 0, 0);
-                } else {
-                    if (kk + 1 < VKK) ldv(fv1, kk + 1);
-#pragma unroll
-                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pr, o[nn], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            store_o(o, 16, true);
-        }
-        if (!more) break;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // every wave is done with V(item) and the side row
-        stage(p.V, p.ldv, Vsm, next, FLASH);
-        item = next;
-    }
-}
-
 // 0 = off (attn_fullrow), 1 = 12-wave kernel; where n == 257: 2 = 16-wave kernel, 3 = + 16-byte output stores (default), 4 = + normalisation
 // behind PV.  Measured at B = 128 (profiles/r03_call5_attention_modes.log): 159.2 / 159.1 / 152.2 / 137.5 us for 1 / 2 / 3 / 4; end to end
 // 121.9 / - / 121.5 / 121.0 ms per 256 images.  4 moves a rounding point away from the reference's (the normalised probabilities are no
 // longer what is rounded to half): its outputs sit ~0.8 bf16 ulp (rms) from the other kernels', at the same distance from fp32 - left
-// selectable, not the default.
+// selectable, not the default.  (An 8-wave form with two query tiles per wave on shared K / V fragments - half the LDS fragment reads per
+// item - was written and measured: bit-identical rows, 162.0 us against 150.6 for mode 3 and 143.3 against 143.4 for mode 4
+// (profiles/r03_call9_attention_8wave.log): two waves per SIMD hide less latency than the halved LDS traffic buys.  Removed.)
 int g_attn_vit = 3;
 #undef V16STAMP
 #ifdef SEEDMI_DEVTOOLS
@@ -1078,18 +737,6 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
-    }
-    if (g_attn_vit >= 5 && nq == V16_N && round_scores) {        // 8-wave kernel, two query tiles per wave: 5 = reference rounding points, 6 = normalisation behind PV
-        static bool attr8_dev[SEEDMI_MAX_DEVICES] = {};
-        if (!attr8_dev[dev]) {
-            (void)hipFuncSetAttribute((const void*)attn_vit8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)attn_vit8_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);
-            attr8_dev[dev] = true;
-        }
-        const dim3 blk8(64 * V8_WAVES);
-        if (g_attn_vit == 5) hipLaunchKernelGGL((attn_vit8_kernel<true, false>), dim3(grid), blk8, V16_LDS_BYTES, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((attn_vit8_kernel<true, true>), dim3(grid), blk8, V16_LDS_BYTES, (hipStream_t)stream, p);
-        return seedmi_check_launch("attn_vit8");
     }
     if (g_attn_vit >= 2 && nq == V16_N && round_scores) {        // (unrounded scores: only tests ask for them; the 12-wave kernel serves those)
         static bool attr16_dev[SEEDMI_MAX_DEVICES] = {};

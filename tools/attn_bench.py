@@ -15,8 +15,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B * N, 3 * C, device="cuda", generator=g).bfloat16()
 out = torch.empty(B * N, C, device="cuda", dtype=torch.bfloat16)
 flops = 4.0 * B * H * N * N * hd
-for trv in (7, 6, 5, 4, 2, 1):                            # 7 / 6 = 8-wave kernel (flash / reference rounding), 5 / 4 = 16-wave (flash / wide stores), 2 = 12-wave, 1 = attn_fullrow
-    L.check(lib.seedmi_set_option(b"attn_vit", {7: 6, 6: 5, 5: 4, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "opt")
+for trv in (5, 4, 3, 2, 1):                               # 5 / 4 / 3 = 16-wave ViT kernel (flash + wide stores / wide stores / plain), 2 = 12-wave, 1 = attn_fullrow
+    L.check(lib.seedmi_set_option(b"attn_vit", {5: 4, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "opt")
     L.check(lib.seedmi_set_option(b"attn_trv", min(trv, 1)), "opt")
     ts = []
     for i in range(12):
