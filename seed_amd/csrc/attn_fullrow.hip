@@ -13,6 +13,7 @@
 // keys {16t + 4g + r}, and V^T fragments are read with the same (g, j) -> key mapping, so no cross-lane
 // movement or LDS round trip is needed for P.
 #include <string.h>
+#include <atomic>
 #include "common.h"
 #include "seedmi_internal.h"
 
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
     }
 }
 
-int g_attn_trv = 1;     // seedmi_set_option("attn_trv", 0|1): hardware transpose read for V (1) or transposed LDS image (0)
+std::atomic<int> g_attn_trv{1};     // seedmi_set_option("attn_trv", 0|1): hardware transpose read for V (1) or transposed LDS image (0)
 
 template <int HD, int NKP, bool CAUSAL, bool ROUND_S, bool TRV>
 int launch_attn_v(const AttnParams& p, int batch, hipStream_t stream) {

@@ -16,6 +16,7 @@
 // fragment's 12th chunk is zeroed in registers, so it is multiplied by 0, and V columns 88..95 are never stored.
 // Same arithmetic and rounding points as attn_fullrow.hip (q*scale -> half, S -> half, P normalised -> half).
 #include <string.h>
+#include <atomic>
 #include "common.h"
 #include "seedmi_internal.h"
 
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
 // selectable, not the default.  (An 8-wave form with two query tiles per wave on shared K / V fragments - half the LDS fragment reads per
 // item - was written and measured: bit-identical rows, 162.0 us against 150.6 for mode 3 and 143.3 against 143.4 for mode 4
 // (profiles/r03_call9_attention_8wave.log): two waves per SIMD hide less latency than the halved LDS traffic buys.  Removed.)
-int g_attn_vit = 3;
+std::atomic<int> g_attn_vit{3};
 #undef V16STAMP
 #ifdef SEEDMI_DEVTOOLS
 unsigned long long* g_attn_dbg = nullptr;

@@ -7,6 +7,7 @@
 //  seedmi_llama_forward           LlamaForCausalLM.forward / LlamaModel.forward / LlamaDecoderLayer.forward
 //                                 (llama_xformer.py:661-743, 496-627, 280-332)
 #include <string.h>
+#include <atomic>
 #include "common.h"
 #include "seedmi_internal.h"
 #include "../../include/seedmi.h"
@@ -227,12 +228,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
     skinny_tile<MT, EPI, NW, NT, PACKED, R>(p, (int)blockIdx.x);
 }
 
-int g_skinny_nt = 1, g_skinny_nw = 0;
+std::atomic<int> g_skinny_nt{1}, g_skinny_nw{0};
 
-int g_skinny_r = 0;
-int g_prefill_tiled = 1;             // seedmi_set_option("prefill_tiled", 0|1): LDS-tiled prefill attention (0 = first-round kernel)
-int g_ablate_norm = 0;               // seedmi_set_option("decode_ablate_norm", 1): timing only, skips the decode RMSNorm launches
-int g_decode_fused = 1;              // seedmi_set_option("decode_fused", 0|1): RoPE + KV append folded into decode attention
+std::atomic<int> g_skinny_r{0};
+std::atomic<int> g_prefill_tiled{1};             // seedmi_set_option("prefill_tiled", 0|1): LDS-tiled prefill attention (0 = first-round kernel)
+std::atomic<int> g_ablate_norm{0};               // seedmi_set_option("decode_ablate_norm", 1): timing only, skips the decode RMSNorm launches
+std::atomic<int> g_decode_fused{1};              // seedmi_set_option("decode_fused", 0|1): RoPE + KV append folded into decode attention
 
 template <int EPI, int NW, bool NT, bool PACKED, int R>
 int launch_skinny_r(const SkinnyParams& p, hipStream_t s) {
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(512) void decode_layers_kernel(const MegaParams p) 
     }
 }
 
-int g_decode_mega = 0;               // seedmi_set_option("decode_persistent", 0|1): all layers of a decode step in one persistent launch
+std::atomic<int> g_decode_mega{0};               // seedmi_set_option("decode_persistent", 0|1): all layers of a decode step in one persistent launch
 #endif
 
 struct LlamaWs { bf16_t *x, *xn, *qkv, *q, *att, *act; unsigned* bar; bf16_t* mega; size_t mega_stride; size_t bytes; };

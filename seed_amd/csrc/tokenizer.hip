@@ -10,6 +10,7 @@
 // per CU a single stream leaves the chip partly idle in every kernel's last round of tiles and during the
 // HBM-bound LayerNorm / attention kernels; the second stream's workgroups fill those holes.  Nothing is allocated
 // per call (streams/events are created once), there is no host sync, and fork/join by events is graph-capturable.
+#include <atomic>
 #include "common.h"
 #include "seedmi_internal.h"
 #include "../../include/seedmi.h"
@@ -36,12 +37,12 @@ struct TokWs {
     size_t bytes;
 };
 
-int g_tok_streamk = 0;                    // seedmi_set_option("tokenize_streamk", 0|1)
-int g_tok_split = 0;                      // seedmi_set_option("tokenize_split_rounds", 0|1): whole rounds of 256x256 tiles + a 128x128 remainder
-int g_tok_tilestats = 0;                  // seedmi_set_option("tokenize_tile_stats", 0|1): LayerNorm statistics by 256-column tile, finalized inside
+std::atomic<int> g_tok_streamk{0};                    // seedmi_set_option("tokenize_streamk", 0|1)
+std::atomic<int> g_tok_split{0};                      // seedmi_set_option("tokenize_split_rounds", 0|1): whole rounds of 256x256 tiles + a 128x128 remainder
+std::atomic<int> g_tok_tilestats{0};                  // seedmi_set_option("tokenize_tile_stats", 0|1): LayerNorm statistics by 256-column tile, finalized inside
                                           // the consuming GEMM (no seedmi_layernorm_stats_finalize launches between the ViT GEMMs)
-int g_tok_vqhead = 1;                     // seedmi_set_option("tokenize_vq_head", 0|1): last head Linear fused into the VQ argmin kernel
-int g_tok_lnfold = 1;                     // seedmi_set_option("tokenize_lnfold", 0|1): LayerNorm folded into qkv / fc1 when the weights carry it
+std::atomic<int> g_tok_vqhead{1};                     // seedmi_set_option("tokenize_vq_head", 0|1): last head Linear fused into the VQ argmin kernel
+std::atomic<int> g_tok_lnfold{1};                     // seedmi_set_option("tokenize_lnfold", 0|1): LayerNorm folded into qkv / fc1 when the weights carry it
 
 TokWs carve(const seedmi_tokenizer_weights_t* w, int B, void* ws) {
     const int grid = w->img_size / w->patch;
@@ -264,7 +265,7 @@ int run_phase(const Part& p, int phase) {
 }
 
 constexpr int SPLIT_MIN_BATCH = 32;      // below this the kernels are too small for a second stream to help
-int g_tok_streams = 2;                    // seedmi_set_option("tokenize_streams", 1|2)
+std::atomic<int> g_tok_streams{2};                    // seedmi_set_option("tokenize_streams", 1|2)
 
 constexpr int MAX_PARTS = 4;
 // side streams and fork/join events of the sub-batch overlap: one set per (thread, device), created on first use and kept for the
@@ -300,7 +301,10 @@ int ensure_forkjoin(ForkJoin** out) {
     return SEEDMI_OK;
 }
 
-int n_parts(int batch) { return (g_tok_streams >= 2 && batch >= SPLIT_MIN_BATCH) ? g_tok_streams : 1; }
+int n_parts(int batch) {
+    const int n = g_tok_streams.load(std::memory_order_relaxed);
+    return (n >= 2 && batch >= SPLIT_MIN_BATCH) ? n : 1;
+}
 int part_size(int batch, int nparts, int i) { return batch / nparts + (i < batch % nparts ? 1 : 0); }
 
 size_t ws_for(const seedmi_tokenizer_weights_t* w, int batch, int nparts) {
