@@ -61,7 +61,7 @@ int seedmi_check_device(void);
  * "tokenize_tile_stats" (0|1: LayerNorm statistics by 256-column tile, finalized inside the consuming GEMM instead of by
  * seedmi_layernorm_stats_finalize launches; large batches only),
  * "skinny_nt" / "skinny_waves" / "skinny_rows"
- * (decode GEMM), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
+ * (decode GEMM), "skinny_splitk" (0 = one tile per workgroup | 1 = balanced split-K where that form would leave its last round of workgroups under 95 % full: the default | 2 = split-K for every covered shape), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
  * (attention kernel selection; attn_vit: 0 off | 1 twelve-wave ViT kernel | 2 sixteen-wave ViT kernel for 257 tokens).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
 int seedmi_set_option(const char* key, int value);
@@ -208,6 +208,19 @@ int seedmi_gemm_skinny_bf16(int M, int N, int K, const void* A, int lda, const v
 int seedmi_gemm_skinny_norm_bf16(int M, int N, int K, const void* A, int a_packed, const void* W_packed, float rms_eps,
                                  const void* residual, int ldr, int epilogue, void* C, int ldc, int c_packed, void* x_packed_out,
                                  void* stream);
+/* The same GEMM in its balanced split-K form (M <= 32, a_packed = 1): 64-row weight tiles, the (tile, k-step) space cut into one equal
+ * contiguous range per resident workgroup, cut tiles summed in a fixed workgroup order through `workspace`
+ * (seedmi_gemm_skinny_workspace_bytes() bytes, 256-byte aligned).  The first 4 KiB of the workspace are flag words: ZERO them once
+ * after allocation (hipMemset); every launch leaves them zero again, and word 1023 is a sticky error word (non-zero = a launch gave
+ * up waiting for a partner workgroup: its result is wrong - only possible when the launch could not be fully resident).  One workspace
+ * serves any number of launches ON ONE STREAM (launches that may overlap need one each).  workspace == NULL, M > 32, a_packed == 0, a
+ * shape whose one-tile-per-workgroup launch fills its rounds of workgroups (seedmi_set_option("skinny_splitk", 2) overrides that) or
+ * "skinny_splitk" 0 select the kernel of seedmi_gemm_skinny_norm_bf16; both give the same values up to the order of the fp32 K
+ * summation. */
+size_t seedmi_gemm_skinny_workspace_bytes(void);
+int seedmi_gemm_skinny_norm_ws_bf16(int M, int N, int K, const void* A, int a_packed, const void* W_packed, float rms_eps,
+                                    const void* residual, int ldr, int epilogue, void* C, int ldc, int c_packed, void* x_packed_out,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 /* rows [rows, cols] (row stride ldx) -> the fragment-major activation layout, no arithmetic. */
 int seedmi_pack_activations_bf16(const void* x, int ldx, void* out_packed, int rows, int cols, void* stream);
 /* The same GEMM on fragment-major weights: tile (16 rows) x k-step (32) blocks of 1 KiB laid out in the MFMA operand's

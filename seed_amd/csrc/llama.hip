@@ -29,6 +29,9 @@ struct SkinnyParams {
     // squares of the activation fragments it streams anyway and scales its accumulators by rsqrt(mean(x^2) + eps) per row
     float norm_eps;              // > 0 enables it
     bf16_t* xp_out;              // optional second copy of a BIAS_RESIDUAL result in the fragment-major activation layout
+#ifdef SEEDMI_DEVTOOLS
+    int abl;                     // timing ablations (seedmi_set_option("skinny_ablate")): 1 no activation loads, 2 no MFMA / norm sums, 4 no reduction / epilogue
+#endif
 };
 
 // stores of the persistent decode kernel's phase outputs: written through to memory (sc0 sc1), so that the other XCDs see them after
@@ -103,6 +106,12 @@ SEEDMI_DEVINL void skinny_tile(const SkinnyParams& p, const int bidx) {
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = tid >> 6;
     const int n0 = bidx * 16 * R;
+#ifdef SEEDMI_DEVTOOLS
+    const int abl = WT ? 0 : p.abl;
+#else
+    constexpr int abl = 0;
+#endif
+    unsigned xacc = 0;                                                // (ablations: keeps the loads alive)
     const int kslice = p.K / NW;
     const int kbeg = wave * kslice;
     // PACKED: fragment-major weights (seedmi_pack_skinny_weights): tile j, k-step s is one contiguous 1 KiB block holding
@@ -142,10 +151,21 @@ SEEDMI_DEVINL void skinny_tile(const SkinnyParams& p, const int bidx) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 wf[u][r] = NT ? __builtin_nontemporal_load((const bf16x8*)(wp[r] + kk * WSTEP)) : *(const bf16x8*)(wp[r] + kk * WSTEP);
+            if (!(abl & 1)) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[u][t] = *(const bf16x8*)(ap[t] + kk * astep);
+                for (int t = 0; t < MT; ++t) af[u][t] = *(const bf16x8*)(ap[t] + kk * astep);
+            }
         }
     };
+    if (abl & 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const uint4 v = make_uint4(0x3c003c00u + lane, 0x3c803c80u, 0xbc003c00u, 0x3c00bc00u + t);
+                a0[u][t] = a1[u][t] = __builtin_bit_cast(bf16x8, v);
+            }
+    }
     float ss[MT];                                                     // sum of squares of this wave's K slice, rows 16t + li
 #pragma unroll
     for (int t = 0; t < MT; ++t) ss[t] = 0.f;
@@ -154,6 +174,13 @@ SEEDMI_DEVINL void skinny_tile(const SkinnyParams& p, const int bidx) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (32 * (U * b + u) < kslice) {
+                if (abl & 2) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { const uint4 v = __builtin_bit_cast(uint4, wf[u][r]); xacc ^= v.x ^ v.y ^ v.z ^ v.w; }
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) { const uint4 v = __builtin_bit_cast(uint4, af[u][t]); xacc ^= v.x ^ v.y ^ v.z ^ v.w; }
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -182,6 +209,11 @@ SEEDMI_DEVINL void skinny_tile(const SkinnyParams& p, const int bidx) {
         if (b + 1 < nb) compute(w1, a1, b + 1);
     }
     __shared__ float red_ss[NW][MT][16];
+    if (abl & 4) {
+        if (xacc == 0x9e3779b9u || acc[0][0][0] == 1234.5f) p.C[lane] = (bf16_t)xacc;
+        return;
+    }
+    if (abl & 2) acc[0][0][0] += (float)(xacc & 1);
     if (do_norm) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {                                // lanes li + 16 g hold the four k-quarters of row 16t + li
@@ -231,6 +263,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(SkinnyParams p) {
 std::atomic<int> g_skinny_nt{1}, g_skinny_nw{0};
 
 std::atomic<int> g_skinny_r{0};
+#ifdef SEEDMI_DEVTOOLS
+std::atomic<int> g_skinny_abl{0};
+#endif
 std::atomic<int> g_prefill_tiled{1};             // seedmi_set_option("prefill_tiled", 0|1): LDS-tiled prefill attention (0 = first-round kernel)
 std::atomic<int> g_ablate_norm{0};               // seedmi_set_option("decode_ablate_norm", 1): timing only, skips the decode RMSNorm launches
 std::atomic<int> g_decode_fused{1};              // seedmi_set_option("decode_fused", 0|1): RoPE + KV append folded into decode attention
@@ -281,6 +316,292 @@ int launch_skinny(const SkinnyParams& p, hipStream_t s) {
     if (w8 && (p.K % 256) == 0)
         return g_skinny_nt ? launch_skinny_nw<EPI, 8, true, PACKED>(p, s) : launch_skinny_nw<EPI, 8, false, PACKED>(p, s);
     return g_skinny_nt ? launch_skinny_nw<EPI, 4, true, PACKED>(p, s) : launch_skinny_nw<EPI, 4, false, PACKED>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------ skinny GEMM, balanced split-K form
+// What round 3's ablations (profiles/r03_call10_decode_gemm_ablations.log) say a 16R-row workgroup loses against a plain stream of the same
+// bytes: the ACTIVATION fragments (every workgroup pulls all of A out of L2: 2 KiB per KiB of weights at R = 1 - 7.5 of down_proj's
+// 25.6 us, 6.4 of gate/up's 45.3), the one-wave epilogue (5.4 us of gate/up) and partly filled last rounds (gate/up: 2.69 rounds of
+// workgroups).  This form fixes the three together:
+//   * 64 weight rows per tile (R = 4): every activation fragment meets four weight fragments - 0.5 KiB of A per KiB of W;
+//   * the (tile, k-step) space is cut into gridDim.x EQUAL contiguous ranges, one resident workgroup each (stream-K): no rounds, no
+//     tail round, any N; a range is at most [tail of a tile][whole tiles][head of a tile];
+//   * inside a segment the 8 waves split the k-steps, reduce through LDS, and wave f finishes FRAGMENT f (row tile r = f / MT,
+//     activation tile t = f % MT): the epilogue is spread over all waves.
+// A tile cut by a range boundary is finished by the workgroup that holds its HEAD (k-step 0; always that workgroup's last segment): the
+// others publish their fp32 image (+ their part of the RMSNorm row sums) write-through and raise a flag, the owner adds them in
+// workgroup order - a fixed summation order, so results are reproducible run to run.  Flags are consumed and cleared by the owner
+// (the flag area is all-zero between launches: graph replays need no epoch).  All workgroups must be resident (grid <= CUs x
+// occupancy, checked by the launcher); waits are bounded and a lost partner is recorded in the sticky error word, like gemm256's stream-K.
+// Logical workgroup order runs XCD by XCD (q = (id % 8) * (G / 8) + id / 8), so an image is produced and consumed on one L2.
+struct SkinnySk {
+    float* slabs;                // [G][SK2_SLAB_FLOATS]
+    unsigned* flags;             // [G] + error word at SK2_FLAG_WORDS - 1
+    int tiles;                   // 64-row tiles
+    int tiles16;                 // 16-row tiles of the packed weight (ceil(N / 16))
+    int ks;                      // k-steps (32 deep) per tile
+};
+constexpr int SK2_R = 4;
+constexpr int SK2_SLAB_FLOATS = 8 * 256 + 64;                  // 8 fragments x (64 lanes x 4) + row sums [2][16] (+ pad)
+constexpr int SK2_FLAG_WORDS = 1024;
+constexpr size_t SK2_WS_BYTES = (size_t)SK2_FLAG_WORDS * 4 + (size_t)(SK2_FLAG_WORDS - 1) * SK2_SLAB_FLOATS * 4;
+
+template <int EPI>
+SEEDMI_DEVINL void skinny_epilogue_frag(const SkinnyParams& p, const f32x4 a, const int m, const int nb_, const float rstd, const uint2 resid,
+                                        const bool resid_ok) {
+    if (m >= p.M || nb_ >= p.N) return;
+    float v[4] = {a[0] * rstd, a[1] * rstd, a[2] * rstd, a[3] * rstd};
+    if (EPI == EPI_BIAS_RESIDUAL) {
+        if (resid_ok) {
+            v[0] = rbf(v[0]) + lo_bf(resid.x); v[1] = rbf(v[1]) + hi_bf(resid.x);
+            v[2] = rbf(v[2]) + lo_bf(resid.y); v[3] = rbf(v[3]) + hi_bf(resid.y);
+        } else {
+            const bf16_t* rp = p.R + (size_t)m * p.ldr + nb_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) v[e] = rbf(v[e]) + bf2f(rp[e]);
+        }
+    }
+    if (EPI == EPI_SWIGLU) {
+        const int kc = nb_ >> 1;                                     // output column of the first (gate, up) pair
+        bf16_t* cp = p.c_packed
+            ? p.C + ((size_t)((m >> 4) * (p.N >> 6) + (kc >> 5)) * 64 + ((kc >> 3) & 3) * 16 + (m & 15)) * 8 + (kc & 7)
+            : p.C + (size_t)m * p.ldc + kc;
+        if (nb_ + 3 < p.N && (p.c_packed || (p.ldc % 2) == 0)) {
+            *(uint32_t*)cp = pack2bf(rbf(silu(rbf(v[0]))) * rbf(v[1]), rbf(silu(rbf(v[2]))) * rbf(v[3]));      // (kc is even: 4-byte aligned)
+        } else {
+            if (nb_ + 1 < p.N) *cp = f2bf(rbf(silu(rbf(v[0]))) * rbf(v[1]));
+            if (nb_ + 3 < p.N) cp[1] = f2bf(rbf(silu(rbf(v[2]))) * rbf(v[3]));
+        }
+    } else {
+        bf16_t* cp = p.C + (size_t)m * p.ldc + nb_;
+        if (nb_ + 4 <= p.N && (p.ldc % 4) == 0) {
+            uint2 w;
+            w.x = pack2bf(v[0], v[1]);
+            w.y = pack2bf(v[2], v[3]);
+            *(uint2*)cp = w;
+            if (p.xp_out)                                             // the next GEMM's fragment-major A operand (row length N)
+                *(uint2*)(p.xp_out + ((size_t)((m >> 4) * (p.N >> 5) + (nb_ >> 5)) * 64 + ((nb_ >> 3) & 3) * 16 + (m & 15)) * 8 + (nb_ & 7)) = w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (nb_ + e < p.N) cp[e] = f2bf(v[e]);
+        }
+    }
+}
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(512) void gemm_skinny_sk_kernel(const SkinnyParams p, const SkinnySk x) {
+    constexpr int R = SK2_R, NW = 8, U = 2, NF = R * MT;
+    __shared__ __attribute__((aligned(16))) float red[NW][NF][64][4];
+    __shared__ float red_ss[NW][MT][16];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const int q = (G % 8) == 0 ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;    // XCD-contiguous order
+    const long long total = (long long)x.tiles * x.ks;
+    const long long u_end = total * (q + 1) / G;
+    const bool do_norm = p.norm_eps > 0.f;
+    const int fr = wave / MT, ft = wave % MT;                        // the fragment this wave finishes (waves >= NF: none)
+    // segment state: tile J, k-steps [ka, kb), this wave's share [s0, s0 + n) and its operand streams
+    int J, ka, kb, n;
+    const bf16_t* wp[R];
+    const bf16_t* ap[MT];
+    auto setup = [&](const long long u) {
+        J = (int)(u / x.ks);
+        ka = (int)(u % x.ks);
+        kb = (int)((u_end - u < (long long)(x.ks - ka)) ? ka + (u_end - u) : x.ks);
+        const int L = kb - ka;
+        const int s0 = ka + L * wave / NW;
+        n = ka + L * (wave + 1) / NW - s0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            wp[r] = p.W + ((size_t)min(R * J + r, x.tiles16 - 1) * x.ks + s0) * 512 + lane * 8;     // (rows past N: re-read the last tile, never stored)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) ap[t] = p.A + ((size_t)t * x.ks + s0) * 512 + lane * 8;
+    };
+    bf16x8 w0[U][R], a0[U][MT], w1[U][R], a1[U][MT];
+    auto load = [&](bf16x8 (&wf)[U][R], bf16x8 (&af)[U][MT], int b) {
+#pragma unroll
+        for (int u2 = 0; u2 < U; ++u2) {
+            const size_t kk = (size_t)min(U * b + u2, n - 1) * 512;      // clamped: out-of-range steps are skipped below
+#pragma unroll
+            for (int r = 0; r < R; ++r) wf[u2][r] = __builtin_nontemporal_load((const bf16x8*)(wp[r] + kk));
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[u2][t] = *(const bf16x8*)(ap[t] + kk);
+        }
+    };
+    long long u = total * q / G;
+    setup(u);
+    if (n > 0) load(w0, a0, 0);
+    for (;;) {
+        const int cJ = J, cka = ka, ckb = kb;
+        const bool owner = cka == 0;
+        // the owner's residual values, requested before the stream starts (the epilogue used to wait for them at the very end)
+        const int e_m = 16 * ft + li, e_n = 64 * cJ + 16 * fr + 4 * g;
+        uint2 resid = make_uint2(0u, 0u);
+        const bool resid_ok = EPI == EPI_BIAS_RESIDUAL && (p.ldr % 4) == 0 && ((uintptr_t)p.R & 7) == 0 && e_n + 4 <= p.N;
+        if (EPI == EPI_BIAS_RESIDUAL && owner && wave < NF && resid_ok && e_m < p.M)
+            resid = *(const uint2*)(p.R + (size_t)e_m * p.ldr + e_n);
+        f32x4 acc[R][MT];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float ss[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) ss[t] = 0.f;
+        if (n > 0) {
+            const int nb = (n + U - 1) / U;
+            auto compute = [&](bf16x8 (&wf)[U][R], bf16x8 (&af)[U][MT], int b) {
+#pragma unroll
+                for (int u2 = 0; u2 < U; ++u2) {
+                    if (U * b + u2 < n) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int t = 0; t < MT; ++t)
+                                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u2][r], af[u2][t], acc[r][t], 0, 0, 0);
+                        if (do_norm) {
+#pragma unroll
+                            for (int t = 0; t < MT; ++t) {
+                                const uint4 xw = __builtin_bit_cast(uint4, af[u2][t]);
+                                const uint32_t w4[4] = {xw.x, xw.y, xw.z, xw.w};
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const float lo = lo_bf(w4[i]), hi = hi_bf(w4[i]);
+                                    ss[t] = fmaf(lo, lo, fmaf(hi, hi, ss[t]));
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            for (int b = 0; b < nb; b += 2) {                         // (batch 0 was requested before the previous segment's reduction)
+                if (b + 1 < nb) load(w1, a1, b + 1);
+                compute(w0, a0, b);
+                if (b + 2 < nb) load(w0, a0, b + 2);
+                if (b + 1 < nb) compute(w1, a1, b + 1);
+            }
+        }
+        u += ckb - cka;
+        const bool more = u < u_end;
+        if (more) {                                                   // the next segment's first batch streams in behind the reduction below
+            setup(u);
+            if (n > 0) load(w0, a0, 0);
+        }
+        if (do_norm) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {                            // lanes li + 16 g hold the four k-quarters of row 16t + li
+                ss[t] += __shfl_xor(ss[t], 16, 64);
+                ss[t] += __shfl_xor(ss[t], 32, 64);
+                if (g == 0) red_ss[wave][t][li] = ss[t];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) *(f32x4*)&red[wave][r * MT + t][lane][0] = acc[r][t];
+        __syncthreads();
+        f32x4 fa = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float tot = 0.f;
+        if (wave < NF) {
+            fa = *(const f32x4*)&red[0][wave][lane][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const f32x4 o = *(const f32x4*)&red[w][wave][lane][0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fa[e] += o[e];
+            }
+            if (do_norm) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += red_ss[w][ft][li];
+            }
+        }
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        if (!owner) {
+            // ---- tail of a tile whose head another workgroup holds: publish.  Protocol of the CDNA guide (G16 R1, write-through form):
+            //      sc1 stores -> EVERY wave drains vmcnt -> workgroup barrier -> one relaxed agent-scope flag store.  (A release fence per
+            //      workgroup + an acquire in the owner, this kernel's first form, wrote back / invalidated whole L2s: 4x slower.)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(x.slabs + (size_t)q * SK2_SLAB_FLOATS, 0, SK2_SLAB_FLOATS * 4,
+                                                                                 0x00020000);
+            if (wave < NF) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, fa), rs, (wave * 256 + lane * 4) * 4, 0, /*sc1*/ 16);
+                if (do_norm && fr == 0 && g == 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), rs, (8 * 256 + ft * 16 + li) * 4, 0, /*sc1*/ 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(x.flags + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ckb < x.ks) {
+                // ---- head of a cut tile: add the later workgroups' images in workgroup order (relaxed poll by one lane, barrier, then
+                //      sc1 loads: they pass this CU's L1 and see the write-through data wherever the publisher ran)
+                const long long tile_end = (long long)(cJ + 1) * x.ks;
+                for (int c = q + 1; c < G && total * c / G < tile_end; ++c) {
+                    if (tid == 0) {
+                        int spins = 0;
+                        while (__hip_atomic_load(x.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22))
+                            __builtin_amdgcn_s_sleep(2);
+                        // consumed: cleared, so that the flag area is all-zero again when the launch ends (graph replays need no epoch)
+                        if (spins < (1 << 22)) __hip_atomic_store(x.flags + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else __hip_atomic_store(x.flags + (SK2_FLAG_WORDS - 1), 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __syncthreads();
+                    if (wave < NF) {
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(x.slabs + (size_t)c * SK2_SLAB_FLOATS, 0,
+                                                                                             SK2_SLAB_FLOATS * 4, 0x00020000);
+                        const f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (wave * 256 + lane * 4) * 4, 0, /*sc1*/ 16));
+                        float ot = 0.f;
+                        if (do_norm) ot = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (8 * 256 + ft * 16 + li) * 4, 0, /*sc1*/ 16));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) fa[e] += o[e];
+                        tot += ot;
+                    }
+                }
+            }
+            if (wave < NF) {
+                // LlamaRMSNorm: variance = mean(x^2) in fp32 (llama_xformer.py:108-110)
+                const float rstd = do_norm ? rsqrtf(tot / (float)p.K + p.norm_eps) : 1.f;
+                skinny_epilogue_frag<EPI>(p, fa, e_m, e_n, rstd, resid, resid_ok);
+            }
+        }
+        if (!more) break;
+        __syncthreads();                                              // (the LDS images are rewritten by the next segment)
+    }
+}
+
+// seedmi_set_option("skinny_splitk", 0|1|2): 0 = always one tile per workgroup (round-1 form); 1 = split-K where that form's last round of
+// workgroups would be under 95 % full (8B: gate/up, 2.69 rounds - 45.4 -> 38.9 us; the other projections fill their rounds and would only pay
+// the hand-off: profiles/r03_call12_decode_splitk.log); 2 = split-K for every shape the kernel covers
+std::atomic<int> g_skinny_sk{1};
+
+// best fill of the last round of workgroups over the row-tile counts launch_skinny_nw may pick (R = 1..3)
+bool skinny_rounds_underfilled(int M, int N) {
+    const int tiles = (N + 15) / 16, n_cu = seedmi_device_cus(seedmi_current_device());
+    double best = 0.0;
+    for (int r = 1; r <= 3; ++r) {
+        if ((tiles % r) || (r == 3 && M > 32) || (r == 2 && tiles < 1024)) continue;
+        const int wgs = tiles / r;
+        const double fill = (double)wgs / ((double)((wgs + n_cu - 1) / n_cu) * n_cu);
+        if (fill > best) best = fill;
+    }
+    return best < 0.95;
+}
+
+template <int EPI>
+int launch_skinny_sk(const SkinnyParams& p, void* ws, hipStream_t s) {
+    SkinnySk x;
+    x.flags = (unsigned*)ws;
+    x.slabs = (float*)((char*)ws + SK2_FLAG_WORDS * 4);
+    x.tiles16 = (p.N + 15) / 16;
+    x.tiles = (x.tiles16 + SK2_R - 1) / SK2_R;
+    x.ks = p.K / 32;
+    int grid = seedmi_device_cus(seedmi_current_device());          // one 512-thread workgroup per CU (174-182 VGPRs): every workgroup is resident
+    if (grid > SK2_FLAG_WORDS - 1) grid = SK2_FLAG_WORDS - 1;
+    const long long total = (long long)x.tiles * x.ks;
+    if (grid > total) grid = (int)total;
+    if (p.M <= 16) hipLaunchKernelGGL((gemm_skinny_sk_kernel<1, EPI>), dim3(grid), dim3(512), 0, s, p, x);
+    else hipLaunchKernelGGL((gemm_skinny_sk_kernel<2, EPI>), dim3(grid), dim3(512), 0, s, p, x);
+    return seedmi_check_launch("gemm_skinny_sk");
 }
 
 // W [N, K] row-major -> fragment-major [ceil(N/16)][K/32][64 lanes][8]; rows beyond N are zero
@@ -731,7 +1052,7 @@ __global__ __launch_bounds__(512) void decode_layers_kernel(const MegaParams p) 
     unsigned phase = 0;
     float* dsm_half = mega_dsm + half * (p.lds_len + 16 * DEC_HD);
     SkinnyParams sp;
-    sp.M = p.M; sp.lda = 0; sp.ldw = 8; sp.a_packed = 1;
+    sp.M = p.M; sp.lda = 0; sp.ldw = 8; sp.a_packed = 1; sp.abl = 0;
     const size_t Mp = (size_t)((p.M + 15) / 16 * 16);
     const bf16_t* xn_in = p.xn;
     for (int l = 0; l < p.layers; ++l) {
@@ -781,7 +1102,7 @@ __global__ __launch_bounds__(512) void decode_layers_kernel(const MegaParams p) 
 std::atomic<int> g_decode_mega{0};               // seedmi_set_option("decode_persistent", 0|1): all layers of a decode step in one persistent launch
 #endif
 
-struct LlamaWs { bf16_t *x, *xn, *qkv, *q, *att, *act; unsigned* bar; bf16_t* mega; size_t mega_stride; size_t bytes; };
+struct LlamaWs { bf16_t *x, *xn, *qkv, *q, *att, *act; unsigned* bar; void* sk; bf16_t* mega; size_t mega_stride; size_t bytes; };
 LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     const size_t M = (size_t)B * T, h = w->hidden, F = w->ffn;
     const size_t Mp = (M + 15) / 16 * 16;            // fragment-major buffers hold whole 16-row tiles
@@ -794,6 +1115,7 @@ LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     t.att = (bf16_t*)c.take(Mp * h * 2);
     t.act = (bf16_t*)c.take(Mp * F * 2);
     t.bar = (unsigned*)c.take(256);                  // persistent decode kernel: arrival counter, error flag
+    t.sk = (T == 1 && M <= 32) ? c.take(SK2_WS_BYTES) : nullptr;      // split-K decode GEMMs: flag words + fp32 images of the cut tiles
     // ... and its per-layer activation buffers (qkv | att | xn after o_proj | act | xn after down), decode steps only: a buffer that
     // is written once per launch never has a stale copy in another XCD's L2, so no phase needs a cache invalidate
     t.mega_stride = 0;
@@ -864,8 +1186,10 @@ int decode_layers_launch(const seedmi_llama_weights_t* w, const LlamaWs& t, int 
 
 // dispatch: decode-sized M goes to the weight-streaming kernel, everything else to the 128x128 MFMA GEMM
 int linear(int M, int N, int K, const void* A, int lda, const void* W, const void* Wp, const void* R, int ldr, int epi,
-           void* C, int ldc, void* s, int a_packed = 0, int c_packed = 0) {
+           void* C, int ldc, void* s, int a_packed = 0, int c_packed = 0, void* sk_ws = nullptr) {
     if (M <= 64 && (K % 128) == 0) {
+        if (Wp && a_packed && sk_ws)
+            return seedmi_gemm_skinny_norm_ws_bf16(M, N, K, A, 1, Wp, 0.f, R, ldr, epi, C, ldc, c_packed, nullptr, sk_ws, SK2_WS_BYTES, s);
         if (Wp) return seedmi_gemm_skinny_packed_bf16(M, N, K, A, lda, Wp, R, ldr, epi, C, ldc, a_packed, c_packed, s);
         return seedmi_gemm_skinny_bf16(M, N, K, A, lda, W, K, R, ldr, epi, C, ldc, s);
     }
@@ -1074,9 +1398,11 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_nt") && (value == 0 || value == 1)) { g_skinny_nt = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
+    if (!strcmp(key, "skinny_splitk") && (value >= 0 && value <= 2)) { g_skinny_sk = value; return SEEDMI_OK; }
     if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
 #ifdef SEEDMI_DEVTOOLS
     if (!strcmp(key, "decode_persistent") && (value >= 0 && value <= 3)) { g_decode_mega = value; return SEEDMI_OK; }
+    if (!strcmp(key, "skinny_ablate") && (value >= 0 && value <= 7)) { g_skinny_abl = value; return SEEDMI_OK; }
 #endif
     if (!strcmp(key, "prefill_tiled") && (value == 0 || value == 1)) { g_prefill_tiled = value; return SEEDMI_OK; }
     if (!strcmp(key, "decode_ablate_norm") && (value == 0 || value == 1)) { g_ablate_norm = value; return SEEDMI_OK; }
@@ -1085,7 +1411,11 @@ int seedmi_llama_set_option(const char* key, int value) {
 
 static int skinny_entry(bool packed, int M, int N, int K, const void* A, int lda, const void* W, int ldw,
                         const void* residual, int ldr, int epilogue, void* C, int ldc, int a_packed, int c_packed,
-                        void* stream, float norm_eps = 0.f, void* xp_out = nullptr) {
+                        void* stream, float norm_eps = 0.f, void* xp_out = nullptr, void* sk_ws = nullptr, size_t sk_ws_bytes = 0) {
+    if (sk_ws && (sk_ws_bytes < SK2_WS_BYTES || ((uintptr_t)sk_ws & 255))) {
+        seedmi_set_error("seedmi_gemm_skinny: workspace %zu bytes (need %zu, 256-byte aligned)", sk_ws_bytes, SK2_WS_BYTES);
+        return SEEDMI_E_ALIGN;
+    }
     if (xp_out && (epilogue != EPI_BIAS_RESIDUAL || (N % 32) || (ldc % 4))) {
         seedmi_set_error("seedmi_gemm_skinny: the fragment-major copy needs the BIAS_RESIDUAL epilogue, N %% 32 == 0 and ldc %% 4 == 0");
         return SEEDMI_E_SHAPE;
@@ -1110,7 +1440,22 @@ static int skinny_entry(bool packed, int M, int N, int K, const void* A, int lda
     p.C = (bf16_t*)C; p.ldc = ldc;
     p.a_packed = a_packed; p.c_packed = c_packed;
     p.norm_eps = norm_eps; p.xp_out = (bf16_t*)xp_out;
+#ifdef SEEDMI_DEVTOOLS
+    p.abl = g_skinny_abl;
+#endif
     hipStream_t s = (hipStream_t)stream;
+    // balanced split-K form: fragment-major W and A, at most two activation row tiles, a caller-owned workspace for the cut tiles
+    const int sk_mode = g_skinny_sk.load(std::memory_order_relaxed);
+    const bool sk = packed && a_packed && sk_ws && M <= 32 && (K % 32) == 0 && (sk_mode == 2 || (sk_mode == 1 && skinny_rounds_underfilled(M, N)));
+    if (sk && epilogue == EPI_BIAS_RESIDUAL && !residual) { seedmi_set_error("seedmi_gemm_skinny: residual epilogue without residual"); return SEEDMI_E_SHAPE; }
+    if (sk) {
+        switch (epilogue) {
+            case EPI_NONE: return launch_skinny_sk<EPI_NONE>(p, sk_ws, s);
+            case EPI_BIAS_RESIDUAL: return launch_skinny_sk<EPI_BIAS_RESIDUAL>(p, sk_ws, s);
+            case EPI_SWIGLU: return launch_skinny_sk<EPI_SWIGLU>(p, sk_ws, s);
+            default: break;
+        }
+    }
     switch (epilogue) {
         case EPI_NONE: return packed ? launch_skinny<EPI_NONE, true>(p, s) : launch_skinny<EPI_NONE, false>(p, s);
         case EPI_BIAS_RESIDUAL:
@@ -1139,6 +1484,15 @@ extern "C" int seedmi_gemm_skinny_norm_bf16(int M, int N, int K, const void* A, 
                                             void* x_packed_out, void* stream) {
     return skinny_entry(true, M, N, K, A, K, W_packed, 8, residual, ldr, epilogue, C, ldc, a_packed, c_packed, stream, rms_eps,
                         x_packed_out);
+}
+
+extern "C" size_t seedmi_gemm_skinny_workspace_bytes(void) { return SK2_WS_BYTES; }
+
+extern "C" int seedmi_gemm_skinny_norm_ws_bf16(int M, int N, int K, const void* A, int a_packed, const void* W_packed, float rms_eps,
+                                               const void* residual, int ldr, int epilogue, void* C, int ldc, int c_packed,
+                                               void* x_packed_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return skinny_entry(true, M, N, K, A, K, W_packed, 8, residual, ldr, epilogue, C, ldc, a_packed, c_packed, stream, rms_eps,
+                        x_packed_out, workspace, workspace_bytes);
 }
 
 extern "C" size_t seedmi_pack_skinny_weights_bytes(int N, int K) {
@@ -1349,6 +1703,11 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
     // consumes a norm computes the row scale itself from the activation fragments it streams, and the GEMM that produces the
     // residual stream also writes its fragment-major copy - no norm launches, no extra pass over x (64 launches per 8B step)
     const bool fold = pk && w->norm_folded && !g_ablate_norm;
+    void* const sk = (pk && t.sk && g_skinny_sk.load(std::memory_order_relaxed)) ? t.sk : nullptr;
+    if (sk && hipMemsetAsync(sk, 0, SK2_FLAG_WORDS * 4, (hipStream_t)stream) != hipSuccess) {       // (the kernels leave it zero; this is the safety net)
+        seedmi_set_error("seedmi_llama_forward: clearing the split-K flag words failed");
+        return SEEDMI_E_HIP;
+    }
     if (fold) CK(seedmi_pack_activations_bf16(t.x, h, t.xn, M, h, stream));
     int mega_done = 0;
 #ifdef SEEDMI_DEVTOOLS
@@ -1359,14 +1718,14 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
         const seedmi_llama_layer_t& L = w->layer[l];
         CK(tap_hidden(l, t.x));
         if (fold) {
-            CK(seedmi_gemm_skinny_norm_bf16(M, 3 * h, h, t.xn, 1, L.qkv_wp, w->rms_eps, nullptr, 0, EPI_NONE, t.qkv, 3 * h, 0, nullptr,
-                                            stream));
+            CK(seedmi_gemm_skinny_norm_ws_bf16(M, 3 * h, h, t.xn, 1, L.qkv_wp, w->rms_eps, nullptr, 0, EPI_NONE, t.qkv, 3 * h, 0, nullptr,
+                                               sk, sk ? SK2_WS_BYTES : 0, stream));
         } else {
             if (pk && g_ablate_norm) {}                      // timing ablation: stale xn
             else if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, M, h, stream));
             else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, h, M, h, stream));
             CK(linear(M, 3 * h, h, t.xn, h, L.qkv_w, (pk || !w->norm_folded) ? L.qkv_wp : nullptr, nullptr, 0, EPI_NONE, t.qkv, 3 * h,
-                      stream, pk, 0));
+                      stream, pk, 0, sk));
         }
         if (T == 1 && g_decode_fused) {
             // RoPE + cache append + attention in one launch (bit-identical to the two-kernel form below)
@@ -1379,18 +1738,19 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
                                            pk, past_len_dev, stream));
         }
         if (fold) {
-            CK(seedmi_gemm_skinny_norm_bf16(M, h, h, t.att, 1, L.o_wp, 0.f, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, 0, t.xn, stream));
-            CK(seedmi_gemm_skinny_norm_bf16(M, 2 * F, h, t.xn, 1, L.gate_up_wp, w->rms_eps, nullptr, 0, EPI_SWIGLU, t.act, F, 1, nullptr,
-                                            stream));
-            CK(seedmi_gemm_skinny_norm_bf16(M, h, F, t.act, 1, L.down_wp, 0.f, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, 0, t.xn, stream));
+            const size_t skb = sk ? SK2_WS_BYTES : 0;
+            CK(seedmi_gemm_skinny_norm_ws_bf16(M, h, h, t.att, 1, L.o_wp, 0.f, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, 0, t.xn, sk, skb, stream));
+            CK(seedmi_gemm_skinny_norm_ws_bf16(M, 2 * F, h, t.xn, 1, L.gate_up_wp, w->rms_eps, nullptr, 0, EPI_SWIGLU, t.act, F, 1, nullptr,
+                                               sk, skb, stream));
+            CK(seedmi_gemm_skinny_norm_ws_bf16(M, h, F, t.act, 1, L.down_wp, 0.f, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, 0, t.xn, sk, skb, stream));
         } else {
-            CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
+            CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0, sk));
             if (pk && g_ablate_norm) {}
             else if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, M, h, stream));
             else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, h, M, h, stream));
             CK(linear(M, 2 * F, h, t.xn, h, L.gate_up_w, (pk || !w->norm_folded) ? L.gate_up_wp : nullptr, nullptr, 0, EPI_SWIGLU, t.act,
-                      F, stream, pk, pk));
-            CK(linear(M, h, F, t.act, F, L.down_w, L.down_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0));
+                      F, stream, pk, pk, sk));
+            CK(linear(M, h, F, t.act, F, L.down_w, L.down_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0, sk));
         }
     }
     const bool pk_head = (batch <= 64 && (h % 128) == 0 && w->lm_head_p);
@@ -1398,8 +1758,8 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
         // final norm + lm_head on the last position of every sequence only (decode fast path)
         if (pk_head && w->norm_folded && !g_ablate_norm) {
             if (!fold) CK(seedmi_pack_activations_bf16(t.x + (size_t)(T - 1) * h, T * h, t.xn, batch, h, stream));
-            CK(seedmi_gemm_skinny_norm_bf16(batch, w->vocab, h, t.xn, 1, w->lm_head_p, w->rms_eps, nullptr, 0, EPI_NONE, logits, ldl, 0,
-                                            nullptr, stream));
+            CK(seedmi_gemm_skinny_norm_ws_bf16(batch, w->vocab, h, t.xn, 1, w->lm_head_p, w->rms_eps, nullptr, 0, EPI_NONE, logits, ldl, 0,
+                                               nullptr, sk, sk ? SK2_WS_BYTES : 0, stream));
         } else {
             if (pk_head) CK(seedmi_rmsnorm_packed_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, batch, h, stream));
             else CK(seedmi_rmsnorm_bf16(t.x + (size_t)(T - 1) * h, T * h, w->norm_w, w->rms_eps, t.xn, h, batch, h, stream));

@@ -102,6 +102,8 @@ SIGNATURES = {
     "seedmi_pack_skinny_weights_bytes": (C.c_size_t, [_i, _i]),
     "seedmi_pack_skinny_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "seedmi_gemm_skinny_norm_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "seedmi_gemm_skinny_workspace_bytes": (C.c_size_t, []),
+    "seedmi_gemm_skinny_norm_ws_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _i, _i, _vp, _i, _i, _vp, _vp, C.c_size_t, _vp]),
     "seedmi_pack_activations_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "seedmi_gemm_skinny_packed_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "seedmi_rmsnorm_packed_bf16": (_i, [_vp, _i, _vp, C.c_float, _vp, _i, _i, _vp]),

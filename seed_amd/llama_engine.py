@@ -122,8 +122,9 @@ class LlamaEngine:
         self.w = w
 
     def _workspace(self, B, T):
-        if self._ws is None or B * T > self._ws_key[0] * self._ws_key[1]:
-            nbytes = self.lib.seedmi_llama_workspace_bytes(C.byref(self.w), B, T)
+        # sized by what the library asks for THIS shape (a decode step carves regions a prefill does not: B * T alone does not order them)
+        nbytes = self.lib.seedmi_llama_workspace_bytes(C.byref(self.w), B, T)
+        if self._ws is None or nbytes > self._ws.numel():
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws_key = (B, T)
         return self._ws

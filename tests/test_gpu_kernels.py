@@ -792,14 +792,48 @@ def _unpack_activations(packed, rows, cols):
     return packed.cpu()[idx]
 
 
+def _skinny_ws(lib):
+    """Zeroed workspace of the split-K decode GEMM (flag words first) + a checker: flags all zero again, error word clear."""
+    nbytes = lib.seedmi_gemm_skinny_workspace_bytes()
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+
+    def check():
+        flags = ws[:4096].view(torch.int32)
+        assert int(flags.abs().sum()) == 0, f"split-K flag words not cleared / error word set: {flags.nonzero().flatten().tolist()[:8]}"
+    return ws, check
+
+
+def _skinny_norm(lib, form, ws, M, N, K, xp, Wp, eps, res, ldr, epi, C, ldc, c_packed, outp, what):
+    """form 'one_tile': seedmi_gemm_skinny_norm_bf16; 'split_k': seedmi_gemm_skinny_norm_ws_bf16 with a workspace."""
+    if form == "split_k":
+        L.check(lib.seedmi_gemm_skinny_norm_ws_bf16(M, N, K, xp, 1, Wp, eps, res, ldr, epi, C, ldc, c_packed, outp, L.ptr(ws), ws.numel(),
+                                                    L.stream_ptr()), what)
+    else:
+        L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, xp, 1, Wp, eps, res, ldr, epi, C, ldc, c_packed, outp, L.stream_ptr()), what)
+
+
+@pytest.mark.parametrize("form", ["one_tile", "split_k"])
 @pytest.mark.parametrize("M,N,K,epi", [(32, 768, 512, "none"), (7, 1536, 1024, "swiglu"), (17, 512, 1408, "residual"),
-                                       (32, 12288, 4096, "none"), (64, 256, 256, "none"),
+                                       (32, 12288, 4096, "none"), (64, 256, 256, "none"), (1, 64, 128, "residual"), (16, 4096, 4096, "residual"),
                                        # SEED-LLaMA-8B decode shapes (config 3): gate|up, down (K = 11008), lm_head (vocab 40194 -> 40208)
                                        (32, 22016, 4096, "swiglu"), (32, 4096, 11008, "residual"), (32, 40208, 4096, "none")])
-def test_skinny_gemm_with_folded_rmsnorm(lib, M, N, K, epi):
-    """seedmi_gemm_skinny_norm_bf16: un-normalised fragment-major rows in, weight * gamma streamed, row scale
-    rsqrt(mean(x^2) + eps) applied to the fp32 accumulators; plus the fragment-major second copy of a residual result and
-    seedmi_pack_activations_bf16 (pure permutation, bit-exact)."""
+def test_skinny_gemm_with_folded_rmsnorm(lib, M, N, K, epi, form):
+    """seedmi_gemm_skinny_norm_bf16 / seedmi_gemm_skinny_norm_ws_bf16 (balanced split-K): un-normalised fragment-major rows in,
+    weight * gamma streamed, row scale rsqrt(mean(x^2) + eps) applied to the fp32 accumulators; plus the fragment-major second copy of a
+    residual result and seedmi_pack_activations_bf16 (pure permutation, bit-exact).  The split-K form must also leave its flag words
+    zero and give the same bits when the launch is repeated (fixed summation order)."""
+    if form == "split_k" and M > 32:
+        pytest.skip("the split-K form covers M <= 32 (two activation row tiles)")
+    ws, ws_check = _skinny_ws(lib) if form == "split_k" else (None, lambda: None)
+    if form == "split_k":
+        L.check(lib.seedmi_set_option(b"skinny_splitk", 2), "skinny_splitk")       # every shape through the split-K kernel (default: by round fill)
+    try:
+        _skinny_folded_rmsnorm_case(lib, M, N, K, epi, form, ws, ws_check)
+    finally:
+        L.check(lib.seedmi_set_option(b"skinny_splitk", 1), "skinny_splitk")
+
+
+def _skinny_folded_rmsnorm_case(lib, M, N, K, epi, form, ws, ws_check):
     gen = torch.Generator().manual_seed(M * 7 + N)
     eps = 1e-6
     x = bf(rand(gen, M, K) * 3.0)
@@ -819,28 +853,45 @@ def test_skinny_gemm_with_folded_rmsnorm(lib, M, N, K, epi):
     y = (x.double() @ Wg.double().t()).float() * rstd                     # fp32 accumulate, scale, then ONE rounding
     if epi == "none":
         C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-        L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, L.ptr(xp), 1, L.ptr(Wp), eps, None, 0, L.EPI_NONE, L.ptr(C), N, 0, None,
-                                                 L.stream_ptr()), "skinny_norm")
+        _skinny_norm(lib, form, ws, M, N, K, L.ptr(xp), L.ptr(Wp), eps, None, 0, L.EPI_NONE, L.ptr(C), N, 0, None, "skinny_norm")
         torch.cuda.synchronize()
         assert_close_bf16(C, r(y), f"skinny+rmsnorm M{M} N{N} K{K}", atol_ulps=1.5, frac=0.998)
+        first = C.clone()
+        C.zero_()
+        _skinny_norm(lib, form, ws, M, N, K, L.ptr(xp), L.ptr(Wp), eps, None, 0, L.EPI_NONE, L.ptr(C), N, 0, None, "skinny_norm again")
+        torch.cuda.synchronize()
+        assert torch.equal(C, first), "a repeated launch gave different bits"
+        ws_check()
     elif epi == "swiglu":
         C = torch.zeros(M, N // 2, dtype=torch.bfloat16, device="cuda")
-        L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, L.ptr(xp), 1, L.ptr(Wp), eps, None, 0, L.EPI_SWIGLU, L.ptr(C), N // 2, 0,
-                                                 None, L.stream_ptr()), "skinny_norm swiglu")
+        _skinny_norm(lib, form, ws, M, N, K, L.ptr(xp), L.ptr(Wp), eps, None, 0, L.EPI_SWIGLU, L.ptr(C), N // 2, 0, None, "skinny_norm swiglu")
         torch.cuda.synchronize()
         yh = r(y)
         gate, up = yh[:, 0::2], yh[:, 1::2]
         want = r(r(torch.nn.functional.silu(gate)) * up)
         assert_close_bf16(C, want, f"skinny+rmsnorm+swiglu M{M}", atol_ulps=2.0, frac=0.995)
+        if (N % 64) == 0:                                                 # the fragment-major output the decode chain uses: same bits, permuted
+            Cp = torch.zeros(rows_p * (N // 2), dtype=torch.bfloat16, device="cuda")
+            _skinny_norm(lib, form, ws, M, N, K, L.ptr(xp), L.ptr(Wp), eps, None, 0, L.EPI_SWIGLU, L.ptr(Cp), N // 2, 1, None, "swiglu packed")
+            torch.cuda.synchronize()
+            assert torch.equal(_unpack_activations(Cp, M, N // 2), C.cpu())
+        ws_check()
     else:
         # residual epilogue without the scaling (rms_eps = 0) and with the fragment-major second copy
         res = bf(rand(gen, M, N))
         Rd = res.bfloat16().cuda()
         C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
         outp = torch.zeros(rows_p * N, dtype=torch.bfloat16, device="cuda")
-        L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, L.ptr(xp), 1, L.ptr(Wp), 0.0, L.ptr(Rd), N, L.EPI_BIAS_RESIDUAL, L.ptr(C), N, 0,
-                                                 L.ptr(outp), L.stream_ptr()), "skinny residual + packed copy")
+        _skinny_norm(lib, form, ws, M, N, K, L.ptr(xp), L.ptr(Wp), 0.0, L.ptr(Rd), N, L.EPI_BIAS_RESIDUAL, L.ptr(C), N, 0, L.ptr(outp),
+                     "skinny residual + packed copy")
         torch.cuda.synchronize()
         want = r(r((x.double() @ Wg.double().t()).float()) + res)
         assert_close_bf16(C, want, f"skinny residual M{M}", atol_ulps=1.5, frac=0.998)
         assert torch.equal(_unpack_activations(outp, M, N), C.cpu())     # the second copy is the same bits, permuted
+        # in place (residual == output), as the decode chain runs o_proj / down_proj on the residual stream
+        inplace = Rd.clone()
+        _skinny_norm(lib, form, ws, M, N, K, L.ptr(xp), L.ptr(Wp), 0.0, L.ptr(inplace), N, L.EPI_BIAS_RESIDUAL, L.ptr(inplace), N, 0, L.ptr(outp),
+                     "skinny residual in place")
+        torch.cuda.synchronize()
+        assert torch.equal(inplace, C), "in-place residual differs from the out-of-place launch"
+        ws_check()

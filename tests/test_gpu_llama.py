@@ -172,9 +172,13 @@ def test_llama8b_width_parity_with_oracle(fold_norm):
     ek, ek16 = _rel(eng.k_cache[1][:B, :, :T0].float(), p32[1][0][:, :, :T0]), _rel(p16[1][0][:, :, :T0], p32[1][0][:, :, :T0])
     print(f"[8B-width layer-1 keys fold={fold_norm}] rel vs fp32 oracle: hip {ek:.3e} / bf16-oracle {ek16:.3e}")
     assert ek < max(1.5 * ek16, 5e-3), (ek, ek16)
-    # free-running greedy: eager loop and hipGraph replay vs the fp32 oracle on confident rows
+    # free-running greedy: eager loop and hipGraph replay vs the fp32 oracle on confident rows.  Confident = the fp32 top-2 gap exceeds both
+    # SURVEY 8d's margin (1e-2 * max|logit|) and 3x the bf16 ORACLE's own largest deviation on that row: at this width the two bf16
+    # pipelines sit 0.11-0.12 (max abs) from fp32, above the 0.07 the first margin alone allows - a row inside that band flips with the
+    # order of an fp32 summation (it did when the split-K decode GEMM changed gate/up's), which is noise, not a defect
     top2 = s32.topk(2, dim=-1).values
-    confident = (top2[..., 0] - top2[..., 1]) > 1e-2 * s32.abs().amax(-1)
+    gap = top2[..., 0] - top2[..., 1]
+    confident = (gap > 1e-2 * s32.abs().amax(-1)) & (gap > 3.0 * (s16 - s32).abs().amax(-1))
     eager, _ = eng.greedy_decode(prompt.cuda(), n_new)
     graphed = eng.greedy_decode_graph(prompt.cuda(), n_new).clone()
     torch.cuda.synchronize()
