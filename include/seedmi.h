@@ -61,7 +61,7 @@ int seedmi_check_device(void);
  * "tokenize_tile_stats" (0|1: LayerNorm statistics by 256-column tile, finalized inside the consuming GEMM instead of by
  * seedmi_layernorm_stats_finalize launches; large batches only),
  * "skinny_nt" / "skinny_waves" / "skinny_rows"
- * (decode GEMM), "skinny_splitk" (0 = one tile per workgroup | 1 = balanced split-K where that form would leave its last round of workgroups under 95 % full: the default | 2 = split-K for every covered shape), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
+ * (decode GEMM), "skinny_splitk" (which kernel seedmi_gemm_skinny_norm_ws_bf16 runs: 0 = the one-tile-per-workgroup kernel | 1 = the split-K kernel, uncut where the shape divides into whole tiles per workgroup: the default | 2 = the split-K kernel, always cut | 3 = the split-K kernel only where the one-tile form would leave its last round of workgroups under 95 % full), "decode_fused" (0|1 RoPE + append inside decode attention), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
  * (attention kernel selection; attn_vit: 0 off | 1 twelve-wave ViT kernel | 2 sixteen-wave ViT kernel for 257 tokens).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
 int seedmi_set_option(const char* key, int value);
@@ -213,10 +213,10 @@ int seedmi_gemm_skinny_norm_bf16(int M, int N, int K, const void* A, int a_packe
  * (seedmi_gemm_skinny_workspace_bytes() bytes, 256-byte aligned).  The first 4 KiB of the workspace are flag words: ZERO them once
  * after allocation (hipMemset); every launch leaves them zero again, and word 1023 is a sticky error word (non-zero = a launch gave
  * up waiting for a partner workgroup: its result is wrong - only possible when the launch could not be fully resident).  One workspace
- * serves any number of launches ON ONE STREAM (launches that may overlap need one each).  workspace == NULL, M > 32, a_packed == 0, a
- * shape whose one-tile-per-workgroup launch fills its rounds of workgroups (seedmi_set_option("skinny_splitk", 2) overrides that) or
- * "skinny_splitk" 0 select the kernel of seedmi_gemm_skinny_norm_bf16; both give the same values up to the order of the fp32 K
- * summation. */
+ * serves any number of launches ON ONE STREAM (launches that may overlap need one each).  A shape that divides into whole tiles per
+ * workgroup (16-row tiles a multiple of the CU count, or of three times it) runs uncut: no hand-off, the workspace untouched.
+ * workspace == NULL, M > 32, a_packed == 0 or seedmi_set_option("skinny_splitk", 0) select the kernel of seedmi_gemm_skinny_norm_bf16;
+ * all forms give the same values up to the order of the fp32 K summation. */
 size_t seedmi_gemm_skinny_workspace_bytes(void);
 int seedmi_gemm_skinny_norm_ws_bf16(int M, int N, int K, const void* A, int a_packed, const void* W_packed, float rms_eps,
                                     const void* residual, int ldr, int epilogue, void* C, int ldc, int c_packed, void* x_packed_out,

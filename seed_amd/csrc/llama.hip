@@ -341,7 +341,6 @@ struct SkinnySk {
     int tiles16;                 // 16-row tiles of the packed weight (ceil(N / 16))
     int ks;                      // k-steps (32 deep) per tile
 };
-constexpr int SK2_R = 4;
 constexpr int SK2_SLAB_FLOATS = 8 * 256 + 64;                  // 8 fragments x (64 lanes x 4) + row sums [2][16] (+ pad)
 constexpr int SK2_FLAG_WORDS = 1024;
 constexpr size_t SK2_WS_BYTES = (size_t)SK2_FLAG_WORDS * 4 + (size_t)(SK2_FLAG_WORDS - 1) * SK2_SLAB_FLOATS * 4;
@@ -388,55 +387,60 @@ SEEDMI_DEVINL void skinny_epilogue_frag(const SkinnyParams& p, const f32x4 a, co
     }
 }
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(512) void gemm_skinny_sk_kernel(const SkinnyParams p, const SkinnySk x) {
-    constexpr int R = SK2_R, NW = 8, U = 2, NF = R * MT;
+template <int MT, int EPI, int R, int WGS = 1>
+__global__ __launch_bounds__(512, WGS == 2 ? 4 : 1) void gemm_skinny_sk_kernel(const SkinnyParams p, const SkinnySk x) {
+    // WGS = 2: two workgroups per CU (<= 128 VGPRs: one k-step per register set), so that one streams while the other reduces
+    constexpr int NW = 8, U = WGS == 2 ? 1 : (R * MT > 4) ? 2 : 4, NF = R * MT;
+    static_assert(NF <= NW, "one fragment per wave");
     __shared__ __attribute__((aligned(16))) float red[NW][NF][64][4];
     __shared__ float red_ss[NW][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;
-    const int q = (G % 8) == 0 ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;    // XCD-contiguous order
-    const long long total = (long long)x.tiles * x.ks;
-    const long long u_end = total * (q + 1) / G;
+    // (32-bit index arithmetic: the launcher checks tiles * ks * (G + 1) < 2^31 - 64-bit divides ahead of the first request cost ~0.5 us)
+    const int total = x.tiles * x.ks;
+    const bool cut = (total % G) != 0 || ((total / G) % x.ks) != 0;                       // (uniform) any tile shared between workgroups?
+    const int q = (cut && (G % 8) == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;    // XCD-contiguous order
+    const int u_end = (int)((unsigned)total * (unsigned)(q + 1) / (unsigned)G);
     const bool do_norm = p.norm_eps > 0.f;
     const int fr = wave / MT, ft = wave % MT;                        // the fragment this wave finishes (waves >= NF: none)
     // segment state: tile J, k-steps [ka, kb), this wave's share [s0, s0 + n) and its operand streams
     int J, ka, kb, n;
     const bf16_t* wp[R];
     const bf16_t* ap[MT];
-    auto setup = [&](const long long u) {
-        J = (int)(u / x.ks);
-        ka = (int)(u % x.ks);
-        kb = (int)((u_end - u < (long long)(x.ks - ka)) ? ka + (u_end - u) : x.ks);
+    auto setup = [&](const int u) {
+        J = u / x.ks;
+        ka = u - J * x.ks;
+        kb = (u_end - u < x.ks - ka) ? ka + (u_end - u) : x.ks;
         const int L = kb - ka;
         const int s0 = ka + L * wave / NW;
         n = ka + L * (wave + 1) / NW - s0;
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            wp[r] = p.W + ((size_t)min(R * J + r, x.tiles16 - 1) * x.ks + s0) * 512 + lane * 8;     // (rows past N: re-read the last tile, never stored)
+            wp[r] = p.W + ((size_t)min(R * J + r, x.tiles16 - 1) * x.ks + s0) * 512;     // (rows past N: re-read the last tile, never stored)
 #pragma unroll
-        for (int t = 0; t < MT; ++t) ap[t] = p.A + ((size_t)t * x.ks + s0) * 512 + lane * 8;
+        for (int t = 0; t < MT; ++t) ap[t] = p.A + ((size_t)t * x.ks + s0) * 512;               // (wave-uniform bases: scalar registers)
     };
+    const int loff = lane * 8;
     bf16x8 w0[U][R], a0[U][MT], w1[U][R], a1[U][MT];
     auto load = [&](bf16x8 (&wf)[U][R], bf16x8 (&af)[U][MT], int b) {
 #pragma unroll
         for (int u2 = 0; u2 < U; ++u2) {
-            const size_t kk = (size_t)min(U * b + u2, n - 1) * 512;      // clamped: out-of-range steps are skipped below
+            const int kk = min(U * b + u2, n - 1) * 512 + loff;          // clamped: out-of-range steps are skipped below
 #pragma unroll
             for (int r = 0; r < R; ++r) wf[u2][r] = __builtin_nontemporal_load((const bf16x8*)(wp[r] + kk));
 #pragma unroll
             for (int t = 0; t < MT; ++t) af[u2][t] = *(const bf16x8*)(ap[t] + kk);
         }
     };
-    long long u = total * q / G;
+    int u = (int)((unsigned)total * (unsigned)q / (unsigned)G);
     setup(u);
     if (n > 0) load(w0, a0, 0);
     for (;;) {
         const int cJ = J, cka = ka, ckb = kb;
         const bool owner = cka == 0;
         // the owner's residual values, requested before the stream starts (the epilogue used to wait for them at the very end)
-        const int e_m = 16 * ft + li, e_n = 64 * cJ + 16 * fr + 4 * g;
+        const int e_m = 16 * ft + li, e_n = 16 * R * cJ + 16 * fr + 4 * g;
         uint2 resid = make_uint2(0u, 0u);
         const bool resid_ok = EPI == EPI_BIAS_RESIDUAL && (p.ldr % 4) == 0 && ((uintptr_t)p.R & 7) == 0 && e_n + 4 <= p.N;
         if (EPI == EPI_BIAS_RESIDUAL && owner && wave < NF && resid_ok && e_m < p.M)
@@ -535,8 +539,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_sk_kernel(const SkinnyParams 
             if (ckb < x.ks) {
                 // ---- head of a cut tile: add the later workgroups' images in workgroup order (relaxed poll by one lane, barrier, then
                 //      sc1 loads: they pass this CU's L1 and see the write-through data wherever the publisher ran)
-                const long long tile_end = (long long)(cJ + 1) * x.ks;
-                for (int c = q + 1; c < G && total * c / G < tile_end; ++c) {
+                const int tile_end = (cJ + 1) * x.ks;
+                for (int c = q + 1; c < G && (int)((unsigned)total * (unsigned)c / (unsigned)G) < tile_end; ++c) {
                     if (tid == 0) {
                         int spins = 0;
                         while (__hip_atomic_load(x.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22))
@@ -569,9 +573,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_sk_kernel(const SkinnyParams 
     }
 }
 
-// seedmi_set_option("skinny_splitk", 0|1|2): 0 = always one tile per workgroup (round-1 form); 1 = split-K where that form's last round of
-// workgroups would be under 95 % full (8B: gate/up, 2.69 rounds - 45.4 -> 38.9 us; the other projections fill their rounds and would only pay
-// the hand-off: profiles/r03_call12_decode_splitk.log); 2 = split-K for every shape the kernel covers
+// seedmi_set_option("skinny_splitk", 0..3): 0 = the round-1 kernel (one tile per workgroup, one-wave epilogue) always; 1 = this kernel, uncut
+// where the shape divides, cut otherwise (see launch_skinny_sk); 2 = this kernel, always cut (R = 4); 3 = this kernel only where the round-1
+// form's last round of workgroups would be under 95 % full (8B: gate/up, 2.69 rounds - 45.4 -> 35.6 us), the round-1 kernel elsewhere
 std::atomic<int> g_skinny_sk{1};
 
 // best fill of the last round of workgroups over the row-tile counts launch_skinny_nw may pick (R = 1..3)
@@ -587,21 +591,43 @@ bool skinny_rounds_underfilled(int M, int N) {
     return best < 0.95;
 }
 
-template <int EPI>
-int launch_skinny_sk(const SkinnyParams& p, void* ws, hipStream_t s) {
+template <int EPI, int R, int WGS = 1>
+int launch_skinny_sk_r(const SkinnyParams& p, void* ws, int grid, hipStream_t s) {
     SkinnySk x;
     x.flags = (unsigned*)ws;
     x.slabs = (float*)((char*)ws + SK2_FLAG_WORDS * 4);
     x.tiles16 = (p.N + 15) / 16;
-    x.tiles = (x.tiles16 + SK2_R - 1) / SK2_R;
+    x.tiles = (x.tiles16 + R - 1) / R;
     x.ks = p.K / 32;
-    int grid = seedmi_device_cus(seedmi_current_device());          // one 512-thread workgroup per CU (174-182 VGPRs): every workgroup is resident
-    if (grid > SK2_FLAG_WORDS - 1) grid = SK2_FLAG_WORDS - 1;
     const long long total = (long long)x.tiles * x.ks;
     if (grid > total) grid = (int)total;
-    if (p.M <= 16) hipLaunchKernelGGL((gemm_skinny_sk_kernel<1, EPI>), dim3(grid), dim3(512), 0, s, p, x);
-    else hipLaunchKernelGGL((gemm_skinny_sk_kernel<2, EPI>), dim3(grid), dim3(512), 0, s, p, x);
+    if (total * (grid + 1) >= (1ll << 31)) {                         // (the kernel's index arithmetic is 32-bit; 8B lm_head: 629 x 128 x 257)
+        seedmi_set_error("seedmi_gemm_skinny: N=%d K=%d is beyond the split-K kernel's index range", p.N, p.K);
+        return SEEDMI_E_SHAPE;
+    }
+    if (p.M <= 16) hipLaunchKernelGGL((gemm_skinny_sk_kernel<1, EPI, R, WGS>), dim3(grid), dim3(512), 0, s, p, x);
+    else hipLaunchKernelGGL((gemm_skinny_sk_kernel<2, EPI, R, WGS>), dim3(grid), dim3(512), 0, s, p, x);
     return seedmi_check_launch("gemm_skinny_sk");
+}
+
+// Row tiles per workgroup tile.  A shape whose 16-row tiles divide into whole R-tiles with a whole number of them per workgroup runs
+// UNCUT (no hand-off at all: 8B q/k/v = 768 tiles -> R = 3, one 48-row tile per CU; o_proj / down = 256 tiles -> R = 1): the kernel is then
+// the one-tile form with the epilogue spread over the waves and the residual requested up front.  Everything else (8B gate/up: 1376
+// tiles, lm_head: 2513) takes R = 4 and the balanced cut.  `force_cut` (seedmi_set_option("skinny_splitk", 2)): R = 4 for every shape.
+template <int EPI>
+int launch_skinny_sk(const SkinnyParams& p, void* ws, int mode, hipStream_t s) {
+    const bool force_cut = mode == 2;
+    int grid = seedmi_device_cus(seedmi_current_device());          // one 512-thread workgroup per CU (up to 182 VGPRs): every workgroup is resident
+    if (grid > SK2_FLAG_WORDS - 1) grid = SK2_FLAG_WORDS - 1;
+    const int tiles16 = (p.N + 15) / 16;
+#ifdef SEEDMI_DEVTOOLS
+    if (mode == 4 && 2 * grid <= SK2_FLAG_WORDS - 1) return launch_skinny_sk_r<EPI, 4, 2>(p, ws, 2 * grid, s);      // (experiment: 2 workgroups per CU)
+#endif
+    if (!force_cut) {
+        if ((tiles16 % 3) == 0 && ((tiles16 / 3) % grid) == 0) return launch_skinny_sk_r<EPI, 3>(p, ws, grid, s);
+        if ((tiles16 % grid) == 0) return launch_skinny_sk_r<EPI, 1>(p, ws, grid, s);
+    }
+    return launch_skinny_sk_r<EPI, 4>(p, ws, grid, s);
 }
 
 // W [N, K] row-major -> fragment-major [ceil(N/16)][K/32][64 lanes][8]; rows beyond N are zero
@@ -1398,7 +1424,10 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_nt") && (value == 0 || value == 1)) { g_skinny_nt = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
-    if (!strcmp(key, "skinny_splitk") && (value >= 0 && value <= 2)) { g_skinny_sk = value; return SEEDMI_OK; }
+    if (!strcmp(key, "skinny_splitk") && (value >= 0 && value <= 3)) { g_skinny_sk = value; return SEEDMI_OK; }
+#ifdef SEEDMI_DEVTOOLS
+    if (!strcmp(key, "skinny_splitk") && value == 4) { g_skinny_sk = value; return SEEDMI_OK; }
+#endif
     if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
 #ifdef SEEDMI_DEVTOOLS
     if (!strcmp(key, "decode_persistent") && (value >= 0 && value <= 3)) { g_decode_mega = value; return SEEDMI_OK; }
@@ -1446,13 +1475,14 @@ static int skinny_entry(bool packed, int M, int N, int K, const void* A, int lda
     hipStream_t s = (hipStream_t)stream;
     // balanced split-K form: fragment-major W and A, at most two activation row tiles, a caller-owned workspace for the cut tiles
     const int sk_mode = g_skinny_sk.load(std::memory_order_relaxed);
-    const bool sk = packed && a_packed && sk_ws && M <= 32 && (K % 32) == 0 && (sk_mode == 2 || (sk_mode == 1 && skinny_rounds_underfilled(M, N)));
+    const bool sk = packed && a_packed && sk_ws && M <= 32 && (K % 32) == 0 && sk_mode != 0 && (sk_mode != 3 || skinny_rounds_underfilled(M, N)) &&
+                    (long long)((N + 15) / 16) * (K / 32) * SK2_FLAG_WORDS < (1ll << 31);      // (the kernel's 32-bit index range)
     if (sk && epilogue == EPI_BIAS_RESIDUAL && !residual) { seedmi_set_error("seedmi_gemm_skinny: residual epilogue without residual"); return SEEDMI_E_SHAPE; }
     if (sk) {
         switch (epilogue) {
-            case EPI_NONE: return launch_skinny_sk<EPI_NONE>(p, sk_ws, s);
-            case EPI_BIAS_RESIDUAL: return launch_skinny_sk<EPI_BIAS_RESIDUAL>(p, sk_ws, s);
-            case EPI_SWIGLU: return launch_skinny_sk<EPI_SWIGLU>(p, sk_ws, s);
+            case EPI_NONE: return launch_skinny_sk<EPI_NONE>(p, sk_ws, sk_mode, s);
+            case EPI_BIAS_RESIDUAL: return launch_skinny_sk<EPI_BIAS_RESIDUAL>(p, sk_ws, sk_mode, s);
+            case EPI_SWIGLU: return launch_skinny_sk<EPI_SWIGLU>(p, sk_ws, sk_mode, s);
             default: break;
         }
     }
@@ -1677,11 +1707,23 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
     const int h = w->hidden, F = w->ffn, H = w->heads, hd = h / H;
     const int M = batch * T;
     const float scale = 1.0f / sqrtf((float)hd);
+    // decode steps (T == 1, M <= 64) keep every GEMM operand in the fragment-major layout end to end:
+    // rmsnorm -> [QKV], attention -> [o_proj], rmsnorm -> [gate|up] -> SwiGLU -> [down]; the residual stream stays row-major
+    const bool pk = (T == 1 && M <= 64 && (h % 128) == 0 && (F % 128) == 0 && w->layer[0].qkv_wp && w->layer[0].o_wp &&
+                     w->layer[0].gate_up_wp && w->layer[0].down_wp);
+    // folded RMSNorm (w->norm_folded: the fragment-major qkv / gate_up / lm_head copies carry weight * gamma): the GEMM that
+    // consumes a norm computes the row scale itself from the activation fragments it streams, and the GEMM that produces the
+    // residual stream also writes its fragment-major copy - no norm launches, no extra pass over x (64 launches per 8B step)
+    const bool fold = pk && w->norm_folded && !g_ablate_norm;
+    void* const sk = (pk && t.sk && g_skinny_sk.load(std::memory_order_relaxed)) ? t.sk : nullptr;
+    const bool fused_first = fold && !inputs_embeds;     // embedding rows, their fragment-major copy and the flag clear in ONE launch
     if (inputs_embeds) {                                 // LlamaModel.forward with inputs_embeds (llama_xformer.py:543-544 skipped)
         if (hipMemcpyAsync(t.x, inputs_embeds, (size_t)M * h * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
             seedmi_set_error("seedmi_llama_forward_io: copying inputs_embeds failed");
             return SEEDMI_E_HIP;
         }
+    } else if (fused_first) {
+        CK(seedmi_embed_rows_decode(ids_i64, w->embed, h, t.x, h, t.xn, M, h, w->vocab, sk, sk ? SK2_FLAG_WORDS : 0, stream));
     } else {
         CK(seedmi_embed_rows(ids_i64, w->embed, h, t.x, h, M, h, w->vocab, stream));
     }
@@ -1695,20 +1737,11 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
         }
         return SEEDMI_OK;
     };
-    // decode steps (T == 1, M <= 64) keep every GEMM operand in the fragment-major layout end to end:
-    // rmsnorm -> [QKV], attention -> [o_proj], rmsnorm -> [gate|up] -> SwiGLU -> [down]; the residual stream stays row-major
-    const bool pk = (T == 1 && M <= 64 && (h % 128) == 0 && (F % 128) == 0 && w->layer[0].qkv_wp && w->layer[0].o_wp &&
-                     w->layer[0].gate_up_wp && w->layer[0].down_wp);
-    // folded RMSNorm (w->norm_folded: the fragment-major qkv / gate_up / lm_head copies carry weight * gamma): the GEMM that
-    // consumes a norm computes the row scale itself from the activation fragments it streams, and the GEMM that produces the
-    // residual stream also writes its fragment-major copy - no norm launches, no extra pass over x (64 launches per 8B step)
-    const bool fold = pk && w->norm_folded && !g_ablate_norm;
-    void* const sk = (pk && t.sk && g_skinny_sk.load(std::memory_order_relaxed)) ? t.sk : nullptr;
-    if (sk && hipMemsetAsync(sk, 0, SK2_FLAG_WORDS * 4, (hipStream_t)stream) != hipSuccess) {       // (the kernels leave it zero; this is the safety net)
-        seedmi_set_error("seedmi_llama_forward: clearing the split-K flag words failed");
+    if (sk && !fused_first && hipMemsetAsync(sk, 0, SK2_FLAG_WORDS * 4, (hipStream_t)stream) != hipSuccess) {     // (the kernels leave the
+        seedmi_set_error("seedmi_llama_forward: clearing the split-K flag words failed");                       //  words zero: safety net)
         return SEEDMI_E_HIP;
     }
-    if (fold) CK(seedmi_pack_activations_bf16(t.x, h, t.xn, M, h, stream));
+    if (fold && !fused_first) CK(seedmi_pack_activations_bf16(t.x, h, t.xn, M, h, stream));
     int mega_done = 0;
 #ifdef SEEDMI_DEVTOOLS
     if (fold && g_decode_fused && !hidden_states)

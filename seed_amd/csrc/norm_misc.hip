@@ -235,6 +235,27 @@ __global__ void embed_rows_kernel(const long long* __restrict__ ids, const bf16_
     }
 }
 
+// The first launch of a decode step: embedding rows -> the residual stream (row-major) AND its fragment-major copy (the layout of
+// pack_rows_kernel below: what the first folded-RMSNorm GEMM reads), and the split-K GEMMs' flag words cleared - one launch where the
+// step used to issue three (embed_rows, a memset node, pack_rows).
+__global__ void embed_rows_decode_kernel(const long long* __restrict__ ids, const bf16_t* __restrict__ table, int ldt,
+                                         bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ out_packed, int n, int cols, int vocab,
+                                         unsigned* __restrict__ zero_words, int n_zero) {
+    const int chunks = cols >> 3;
+    const long long total = (long long)n * chunks;
+    const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = t0; i < n_zero; i += step) zero_words[i] = 0u;
+    for (long long idx = t0; idx < total; idx += step) {
+        const int c = (int)(idx % chunks);
+        const int m = (int)(idx / chunks);
+        long long id = ids[m];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const uint4 v = *(const uint4*)(table + id * ldt + 8 * c);
+        *(uint4*)(out + (size_t)m * ldo + 8 * c) = v;
+        *(uint4*)(out_packed + ((size_t)((m >> 4) * (cols >> 5) + (c >> 2)) * 64 + (c & 3) * 16 + (m & 15)) * 8) = v;
+    }
+}
+
 // qkv [B*T, 3*H*hd] (q|k|v) -> q_out [B*T, H*hd] rotated; K/V caches [B][H][Tmax][hd] appended at pos_base+t.
 // RoPE arithmetic in the activation dtype with the reference's rounding points:
 //   half(half(x*cos) + half(rotate_half(x)*sin)), cos/sin tables pre-rounded to half  (llama_xformer.py:147-168)
@@ -444,6 +465,19 @@ extern "C" int seedmi_embed_rows(const void* ids_i64, const void* table, int ldt
     hipLaunchKernelGGL(embed_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)ids_i64, (const bf16_t*)table, ldt, (bf16_t*)out, ldo, n, cols, vocab);
     return seedmi_check_launch("embed_rows");
+}
+
+int seedmi_embed_rows_decode(const void* ids_i64, const void* table, int ldt, void* out, int ldo, void* out_packed, int n, int cols,
+                             int vocab, void* zero_words, int n_zero, void* stream) {
+    if (n <= 0 || cols % 32 || ldt % 8 || ldo % 8 || n_zero < 0 || (n_zero > 0 && !zero_words)) {
+        seedmi_set_error("seedmi_embed_rows_decode: bad shape");
+        return SEEDMI_E_SHAPE;
+    }
+    const long long total = (long long)n * (cols / 8);
+    hipLaunchKernelGGL(embed_rows_decode_kernel, dim3(grid_for(total > n_zero ? total : n_zero, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)ids_i64, (const bf16_t*)table, ldt, (bf16_t*)out, ldo, (bf16_t*)out_packed, n, cols, vocab,
+                       (unsigned*)zero_words, n_zero);
+    return seedmi_check_launch("embed_rows_decode");
 }
 
 extern "C" int seedmi_rope_kv_append(const void* qkv, int ldqkv, const void* pos_ids_i64, const void* cos_t,

@@ -32,5 +32,8 @@ int seedmi_attn_vit_set(int v);
 
 // per-device launch state (function attributes and the CU count belong to a device, not to the process): capi.hip
 #define SEEDMI_MAX_DEVICES 64
+// first launch of a decode step (norm_misc.hip): embedding rows -> row-major + fragment-major copies, n_zero 32-bit words cleared
+int seedmi_embed_rows_decode(const void* ids_i64, const void* table, int ldt, void* out, int ldo, void* out_packed, int n, int cols,
+                             int vocab, void* zero_words, int n_zero, void* stream);
 int seedmi_current_device(void);          // hipGetDevice, clamped to [0, SEEDMI_MAX_DEVICES)
 int seedmi_device_cus(int dev);           // multiProcessorCount of that device (cached)

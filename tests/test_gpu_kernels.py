@@ -804,15 +804,15 @@ def _skinny_ws(lib):
 
 
 def _skinny_norm(lib, form, ws, M, N, K, xp, Wp, eps, res, ldr, epi, C, ldc, c_packed, outp, what):
-    """form 'one_tile': seedmi_gemm_skinny_norm_bf16; 'split_k': seedmi_gemm_skinny_norm_ws_bf16 with a workspace."""
-    if form == "split_k":
+    """form 'one_tile': seedmi_gemm_skinny_norm_bf16; otherwise seedmi_gemm_skinny_norm_ws_bf16 with a workspace."""
+    if form != "one_tile":
         L.check(lib.seedmi_gemm_skinny_norm_ws_bf16(M, N, K, xp, 1, Wp, eps, res, ldr, epi, C, ldc, c_packed, outp, L.ptr(ws), ws.numel(),
                                                     L.stream_ptr()), what)
     else:
         L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, xp, 1, Wp, eps, res, ldr, epi, C, ldc, c_packed, outp, L.stream_ptr()), what)
 
 
-@pytest.mark.parametrize("form", ["one_tile", "split_k"])
+@pytest.mark.parametrize("form", ["one_tile", "split_k_by_shape", "split_k_cut"])
 @pytest.mark.parametrize("M,N,K,epi", [(32, 768, 512, "none"), (7, 1536, 1024, "swiglu"), (17, 512, 1408, "residual"),
                                        (32, 12288, 4096, "none"), (64, 256, 256, "none"), (1, 64, 128, "residual"), (16, 4096, 4096, "residual"),
                                        # SEED-LLaMA-8B decode shapes (config 3): gate|up, down (K = 11008), lm_head (vocab 40194 -> 40208)
@@ -822,11 +822,11 @@ def test_skinny_gemm_with_folded_rmsnorm(lib, M, N, K, epi, form):
     weight * gamma streamed, row scale rsqrt(mean(x^2) + eps) applied to the fp32 accumulators; plus the fragment-major second copy of a
     residual result and seedmi_pack_activations_bf16 (pure permutation, bit-exact).  The split-K form must also leave its flag words
     zero and give the same bits when the launch is repeated (fixed summation order)."""
-    if form == "split_k" and M > 32:
+    if form != "one_tile" and M > 32:
         pytest.skip("the split-K form covers M <= 32 (two activation row tiles)")
-    ws, ws_check = _skinny_ws(lib) if form == "split_k" else (None, lambda: None)
-    if form == "split_k":
-        L.check(lib.seedmi_set_option(b"skinny_splitk", 2), "skinny_splitk")       # every shape through the split-K kernel (default: by round fill)
+    ws, ws_check = _skinny_ws(lib) if form != "one_tile" else (None, lambda: None)
+    if form == "split_k_cut":
+        L.check(lib.seedmi_set_option(b"skinny_splitk", 2), "skinny_splitk")       # 64-row tiles and the balanced cut for every shape (default: uncut where the shape divides)
     try:
         _skinny_folded_rmsnorm_case(lib, M, N, K, epi, form, ws, ws_check)
     finally:

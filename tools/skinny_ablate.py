@@ -60,10 +60,11 @@ for name, N, K, epi, eps in [("qkv", 12288, 4096, L.EPI_NONE, 1e-6), ("o", 4096,
         L.check(lib.seedmi_gemm_skinny_norm_ws_bf16(M, N, K, L.ptr(Ap), 1, L.ptr(Wp), eps, res, N, epi, L.ptr(C), ncol,
                                                     1 if epi == L.EPI_SWIGLU else 0, xp, L.ptr(ws), ws.numel(), L.stream_ptr()), "skinny sk")
 
-    L.check(lib.seedmi_set_option(b"skinny_splitk", 2), "skinny_splitk")
-    us = timed(run_sk)
+    for mode, tag in ((1, "split-K kernel, by shape"), (2, "split-K kernel, cut"), (4, "cut, 2 workgroups per CU")):
+        L.check(lib.seedmi_set_option(b"skinny_splitk", mode), "skinny_splitk")
+        us = timed(run_sk)
+        line.append(f"{tag}: {us:5.1f}us {N * K * 2 / us / 1e6:4.2f}TB/s")
     L.check(lib.seedmi_set_option(b"skinny_splitk", 1), "skinny_splitk")
-    line.append(f"split-K: {us:5.1f}us {N * K * 2 / us / 1e6:4.2f}TB/s")
     assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "flag words"
     for abl in ABLS:
         L.check(lib.seedmi_set_option(b"skinny_ablate", abl), "skinny_ablate")
