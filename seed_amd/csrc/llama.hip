@@ -268,6 +268,9 @@ std::atomic<int> g_skinny_abl{0};
 #endif
 std::atomic<int> g_prefill_tiled{1};             // seedmi_set_option("prefill_tiled", 0|1): LDS-tiled prefill attention (0 = first-round kernel)
 std::atomic<int> g_ablate_norm{0};               // seedmi_set_option("decode_ablate_norm", 1): timing only, skips the decode RMSNorm launches
+// seedmi_set_option("decode_attn_early", 0|1|2): cached rows requested ahead of the rotation (1 keys, 2 keys + values).  Interleaved graphs
+// (tools/decode_ab.py, profiles/r03_decode_ab.json): 3.454 / 3.415 ms per 8B step for 0 / 1 (twice), 2 = level with 0 (128 VGPRs)
+std::atomic<int> g_decode_attn_early{1};
 std::atomic<int> g_decode_fused{1};              // seedmi_set_option("decode_fused", 0|1): RoPE + KV append folded into decode attention
 
 template <int EPI, int NW, bool NT, bool PACKED, int R>
@@ -340,6 +343,9 @@ struct SkinnySk {
     int tiles;                   // 64-row tiles
     int tiles16;                 // 16-row tiles of the packed weight (ceil(N / 16))
     int ks;                      // k-steps (32 deep) per tile
+    int per, rem;                // the (tile, k-step) space in gridDim.x ranges: `per` units each, the first `rem` ranges one more
+    int cut;                     // any tile shared between workgroups?
+    float ks_inv;                // 1 / ks (unit -> tile without an integer divide ahead of the first request)
 };
 constexpr int SK2_SLAB_FLOATS = 8 * 256 + 64;                  // 8 fragments x (64 lanes x 4) + row sums [2][16] (+ pad)
 constexpr int SK2_FLAG_WORDS = 1024;
@@ -397,11 +403,11 @@ __global__ __launch_bounds__(512, WGS == 2 ? 4 : 1) void gemm_skinny_sk_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;
-    // (32-bit index arithmetic: the launcher checks tiles * ks * (G + 1) < 2^31 - 64-bit divides ahead of the first request cost ~0.5 us)
-    const int total = x.tiles * x.ks;
-    const bool cut = (total % G) != 0 || ((total / G) % x.ks) != 0;                       // (uniform) any tile shared between workgroups?
+    // (32-bit index arithmetic, no integer divides ahead of the first request: ~130 instructions / 0.5 us of the first form's prologue)
+    const bool cut = x.cut != 0;                                                                          // (uniform)
     const int q = (cut && (G % 8) == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;    // XCD-contiguous order
-    const int u_end = (int)((unsigned)total * (unsigned)(q + 1) / (unsigned)G);
+    auto range_start = [&](const int c) { return c * x.per + min(c, x.rem); };
+    const int u_end = range_start(q + 1);
     const bool do_norm = p.norm_eps > 0.f;
     const int fr = wave / MT, ft = wave % MT;                        // the fragment this wave finishes (waves >= NF: none)
     // segment state: tile J, k-steps [ka, kb), this wave's share [s0, s0 + n) and its operand streams
@@ -409,7 +415,8 @@ __global__ __launch_bounds__(512, WGS == 2 ? 4 : 1) void gemm_skinny_sk_kernel(c
     const bf16_t* wp[R];
     const bf16_t* ap[MT];
     auto setup = [&](const int u) {
-        J = u / x.ks;
+        J = (int)((float)u * x.ks_inv);                                // (u < 2^24: exact up to one, fixed below)
+        J += ((J + 1) * x.ks <= u) - (J * x.ks > u);
         ka = u - J * x.ks;
         kb = (u_end - u < x.ks - ka) ? ka + (u_end - u) : x.ks;
         const int L = kb - ka;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(512, WGS == 2 ? 4 : 1) void gemm_skinny_sk_kernel(c
             for (int t = 0; t < MT; ++t) af[u2][t] = *(const bf16x8*)(ap[t] + kk);
         }
     };
-    int u = (int)((unsigned)total * (unsigned)q / (unsigned)G);
+    int u = range_start(q);
     setup(u);
     if (n > 0) load(w0, a0, 0);
     for (;;) {
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(512, WGS == 2 ? 4 : 1) void gemm_skinny_sk_kernel(c
                 // ---- head of a cut tile: add the later workgroups' images in workgroup order (relaxed poll by one lane, barrier, then
                 //      sc1 loads: they pass this CU's L1 and see the write-through data wherever the publisher ran)
                 const int tile_end = (cJ + 1) * x.ks;
-                for (int c = q + 1; c < G && (int)((unsigned)total * (unsigned)c / (unsigned)G) < tile_end; ++c) {
+                for (int c = q + 1; c < G && range_start(c) < tile_end; ++c) {
                     if (tid == 0) {
                         int spins = 0;
                         while (__hip_atomic_load(x.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22))
@@ -601,10 +608,14 @@ int launch_skinny_sk_r(const SkinnyParams& p, void* ws, int grid, hipStream_t s)
     x.ks = p.K / 32;
     const long long total = (long long)x.tiles * x.ks;
     if (grid > total) grid = (int)total;
-    if (total * (grid + 1) >= (1ll << 31)) {                         // (the kernel's index arithmetic is 32-bit; 8B lm_head: 629 x 128 x 257)
+    if (total >= (1ll << 24)) {                                      // (unit -> tile goes through an fp32 product; 8B lm_head: 629 x 128 = 80 512 units)
         seedmi_set_error("seedmi_gemm_skinny: N=%d K=%d is beyond the split-K kernel's index range", p.N, p.K);
         return SEEDMI_E_SHAPE;
     }
+    x.per = (int)(total / grid);
+    x.rem = (int)(total % grid);
+    x.cut = (x.rem != 0 || (x.per % x.ks) != 0) ? 1 : 0;
+    x.ks_inv = 1.0f / (float)x.ks;
     if (p.M <= 16) hipLaunchKernelGGL((gemm_skinny_sk_kernel<1, EPI, R, WGS>), dim3(grid), dim3(512), 0, s, p, x);
     else hipLaunchKernelGGL((gemm_skinny_sk_kernel<2, EPI, R, WGS>), dim3(grid), dim3(512), 0, s, p, x);
     return seedmi_check_launch("gemm_skinny_sk");
@@ -732,7 +743,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 // floats) and `wred` (4 floats).  Called by the stand-alone kernel (one item per workgroup) and by the persistent decode kernel (two
 // 256-thread halves of a workgroup, each with its own LDS slices; every thread of the workgroup reaches the four barriers whether its
 // half has an item (`active`) or not).
-template <bool WT = false>
+// EARLY (stand-alone kernel, seedmi_set_option("decode_attn_early")): 1 = the first batch of cached KEY rows is requested before the
+// rotation (whose operands come from a different buffer - the kernel used to pay that round trip first, and the cache append stores that
+// follow the rotation kept hipcc from hoisting the loads itself); 2 = the first batch of VALUE rows too.  Same arithmetic, same order.
+template <bool WT = false, int EARLY = 0>
 SEEDMI_DEVINL void attn_decode_item(const int item, const int tid, float* dsm, float* wred, const bool active,
                                     const bf16_t* __restrict__ qkv, int ldqkv, const long long* __restrict__ pos_ids,
                                     const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t, bf16_t* __restrict__ kc,
@@ -752,6 +766,22 @@ SEEDMI_DEVINL void attn_decode_item(const int item, const int tid, float* dsm, f
     bf16_t* vb = vc + ((size_t)b * H + h) * tmax * DEC_HD;
     long long pos = pos_ids ? pos_ids[b] : (long long)past;
     pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);           // cos/sin tables have max_pos rows
+    constexpr int DU = 8;
+    uint4 kr0[DU], vr0[DU];                         // EARLY: the first batch of this thread's key / value rows (j = ks + 16 u < past)
+    if (EARLY >= 1) {
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int j = ks + 16 * u;
+            if (j < kv_len - 1) kr0[u] = *(const uint4*)(kb + (size_t)j * DEC_HD + 8 * c);
+        }
+    }
+    if (EARLY >= 2) {
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int j = ks + 16 * u;
+            if (j < kv_len - 1) vr0[u] = *(const uint4*)(vb + (size_t)j * DEC_HD + 8 * c);
+        }
+    }
     // rotate q and the new key: element i pairs with i +- 64, i.e. chunk c with chunk c ^ 8
     float qv[8], kn[8];
     uint4 vnew = make_uint4(0, 0, 0, 0);
@@ -787,16 +817,16 @@ SEEDMI_DEVINL void attn_decode_item(const int item, const int tid, float* dsm, f
     // scores: cached keys from HBM, the new key (j == past) from registers.  The key rows of a thread (j = ks, ks + 16, ...) are
     // requested DU at a time before any of them is used: one exposed memory latency per DU rows instead of one per row (at ctx 123 the
     // un-batched loop was 8 dependent round trips for QK^T and 8 more for PV - most of this kernel's 20 us)
-    constexpr int DU = 8;
-    // (requesting the first DU value rows together with the key rows - they do not depend on the softmax - was tried: 16.4 vs 14.4 us
-    // per launch at ctx 123; 116 instead of 78 VGPRs and twice the loads ahead of the first use)
+    // (round 2: requesting the first DU value rows together with the key rows, AFTER the rotation, was tried: 16.4 vs 14.4 us per launch at
+    // ctx 123; 116 instead of 78 VGPRs and twice the loads ahead of the first use)
     float lmax = -INFINITY;
     for (int j0 = ks; j0 < kv_len; j0 += 16 * DU) {
         uint4 kr[DU];
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
             const int j = j0 + 16 * u;
-            if (j < past) kr[u] = *(const uint4*)(kb + (size_t)j * DEC_HD + 8 * c);
+            if (EARLY >= 1 && j0 == ks) kr[u] = kr0[u];
+            else if (j < past) kr[u] = *(const uint4*)(kb + (size_t)j * DEC_HD + 8 * c);
         }
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
@@ -839,7 +869,8 @@ SEEDMI_DEVINL void attn_decode_item(const int item, const int tid, float* dsm, f
         for (int u = 0; u < DU; ++u) {
             const int j = j0 + 16 * u;
             vr[u] = vnew;
-            if (j < past) vr[u] = *(const uint4*)(vb + (size_t)j * DEC_HD + 8 * c);
+            if (EARLY >= 2 && j0 == ks) { if (j < past) vr[u] = vr0[u]; }
+            else if (j < past) vr[u] = *(const uint4*)(vb + (size_t)j * DEC_HD + 8 * c);
         }
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
@@ -866,6 +897,7 @@ SEEDMI_DEVINL void attn_decode_item(const int item, const int tid, float* dsm, f
     }
 }
 
+template <int EARLY>
 __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __restrict__ qkv, int ldqkv,
                                                                const long long* __restrict__ pos_ids,
                                                                const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t,
@@ -875,8 +907,8 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
                                                                const int* __restrict__ past_dev, int max_pos, int past_stride) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     __shared__ float wred[4];
-    attn_decode_item((int)blockIdx.x, (int)threadIdx.x, dsm, wred, true, qkv, ldqkv, pos_ids, cos_t, sin_t, kc, vc, out, ldo, H, tmax,
-                     past_arg, scale, out_packed, lds_len, past_dev, max_pos, past_stride);
+    attn_decode_item<false, EARLY>((int)blockIdx.x, (int)threadIdx.x, dsm, wred, true, qkv, ldqkv, pos_ids, cos_t, sin_t, kc, vc, out, ldo, H,
+                                   tmax, past_arg, scale, out_packed, lds_len, past_dev, max_pos, past_stride);
 }
 
 // ------------------------------------------------------------------------------------------------ prefill attention
@@ -1429,6 +1461,7 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_splitk") && value == 4) { g_skinny_sk = value; return SEEDMI_OK; }
 #endif
     if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
+    if (!strcmp(key, "decode_attn_early") && (value >= 0 && value <= 2)) { g_decode_attn_early = value; return SEEDMI_OK; }
 #ifdef SEEDMI_DEVTOOLS
     if (!strcmp(key, "decode_persistent") && (value >= 0 && value <= 3)) { g_decode_mega = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_ablate") && (value >= 0 && value <= 7)) { g_skinny_abl = value; return SEEDMI_OK; }
@@ -1476,7 +1509,7 @@ static int skinny_entry(bool packed, int M, int N, int K, const void* A, int lda
     // balanced split-K form: fragment-major W and A, at most two activation row tiles, a caller-owned workspace for the cut tiles
     const int sk_mode = g_skinny_sk.load(std::memory_order_relaxed);
     const bool sk = packed && a_packed && sk_ws && M <= 32 && (K % 32) == 0 && sk_mode != 0 && (sk_mode != 3 || skinny_rounds_underfilled(M, N)) &&
-                    (long long)((N + 15) / 16) * (K / 32) * SK2_FLAG_WORDS < (1ll << 31);      // (the kernel's 32-bit index range)
+                    (long long)((N + 15) / 16) * (K / 32) < (1ll << 24);                       // (the kernel's index range)
     if (sk && epilogue == EPI_BIAS_RESIDUAL && !residual) { seedmi_set_error("seedmi_gemm_skinny: residual epilogue without residual"); return SEEDMI_E_SHAPE; }
     if (sk) {
         switch (epilogue) {
@@ -1572,13 +1605,22 @@ static int decode_attention_launch(const void* qkv, int ldqkv, const void* pos_i
     static bool attr_set_dev[SEEDMI_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[seedmi_current_device()];
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_decode_rope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_decode_rope_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_decode_rope_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_decode_rope_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_decode_rope_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv,
-                       (const long long*)pos_ids_i64, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
-                       (bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, past_len, scale, out_packed, lds_len,
-                       (const int*)past_len_dev, max_pos, past_stride);
+#define SEEDMI_LAUNCH_DECODE_ATTN(E)                                                                                                   \
+    hipLaunchKernelGGL(attn_decode_rope_kernel<E>, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv,        \
+                       (const long long*)pos_ids_i64, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,                   \
+                       (bf16_t*)v_cache, (bf16_t*)out, ldo, H, tmax, past_len, scale, out_packed, lds_len,                            \
+                       (const int*)past_len_dev, max_pos, past_stride)
+    switch (g_decode_attn_early.load(std::memory_order_relaxed)) {
+        case 0: SEEDMI_LAUNCH_DECODE_ATTN(0); break;
+        case 2: SEEDMI_LAUNCH_DECODE_ATTN(2); break;
+        default: SEEDMI_LAUNCH_DECODE_ATTN(1); break;
+    }
+#undef SEEDMI_LAUNCH_DECODE_ATTN
     return seedmi_check_launch("attn_decode_rope");
 }
 

@@ -729,13 +729,23 @@ def test_rope_and_llama_attention(lib, prefill_variant, B, T, H, past):
     assert_close_bf16(out, want, f"llama_attention B{B} T{T} past{past}", atol_ulps=2.5, frac=0.995)
 
 
+@pytest.mark.parametrize("early", [0, 1, 2], ids=["rows_after_rotation", "keys_early", "keys_values_early"])
 @pytest.mark.parametrize("B,H,past,dev_len,packed", [(3, 4, 0, False, False), (2, 2, 37, False, False), (32, 2, 100, True, True),
-                                                      (17, 3, 126, True, False)])
-def test_fused_decode_attention_equals_rope_then_attention(lib, B, H, past, dev_len, packed):
+                                                      (17, 3, 126, True, False), (5, 2, 129, True, True), (4, 3, 300, False, False)])
+def test_fused_decode_attention_equals_rope_then_attention(lib, B, H, past, dev_len, packed, early):
     """seedmi_llama_decode_attention_bf16 (RoPE + cache append + attention, one launch) against the two-kernel form on the same
     inputs: rotated key / value rows in the cache and the attention output must be BIT-identical, with the cache length as
-    a launch argument or read from device memory, row-major or fragment-major output."""
-    hd, tmax, T = 128, 128, 1
+    a launch argument or read from device memory, row-major or fragment-major output, for every request order of the cached rows
+    (seedmi_set_option("decode_attn_early")) and for caches of one, two and three 128-row batches."""
+    L.check(lib.seedmi_set_option(b"decode_attn_early", early), "decode_attn_early")
+    try:
+        _fused_decode_attention_case(lib, B, H, past, dev_len, packed)
+    finally:
+        L.check(lib.seedmi_set_option(b"decode_attn_early", 1), "decode_attn_early")
+
+
+def _fused_decode_attention_case(lib, B, H, past, dev_len, packed):
+    hd, tmax, T = 128, 128 if past < 127 else 384, 1
     gen = torch.Generator().manual_seed(1000 + B + past)
     h = H * hd
     cos_t, sin_t = _rope_tables(tmax, hd)
