@@ -109,7 +109,7 @@ def qkv_gemm_roofline(batch):
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    for name in ("r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
+    for name in ("r03_pmc_qkv_gemm256.json", "r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if batch == 256 and os.path.exists(pmc):
             # bytes past the L2s per launch from rocprofv3 --pmc passes of this same kernel/shape (tools/pmc_qkv.sh: PMC counters
@@ -117,9 +117,9 @@ def qkv_gemm_roofline(batch):
             # note in MI355X_MICROARCH.md, both in KiB)
             d = json.load(open(pmc))
             traffic = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
-            traffic_src = "profiles/" + name
+            traffic_src = "profiles/" + name + " (rocprofv3 --pmc passes of this launch, tools/pmc_qkv.sh; NOT measured in this run)"
             break
-    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS, LayerNorm fold>, persistent (ViT norm1 + QKV: M=%d K=%d N=%d)" % (M, K, N),
+    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS, LayerNorm fold, schedule 31>, persistent (ViT norm1 + QKV: M=%d K=%d N=%d)" % (M, K, N),
             "plain_linear": {"avg_launch_ms": round(plain_avg_ms, 4), "achieved": round(flops / (plain_avg_ms * 1e-3) / 1e12, 1)},
             "with_streamk_tail": {"avg_launch_ms": round(sk_avg_ms, 4), "achieved": round(flops / (sk_avg_ms * 1e-3) / 1e12, 1)},
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -214,7 +214,7 @@ def cpu_baseline(n_images):
 
 
 def _decode_traffic_ratio():
-    for name in ("r02_pmc_decode_gemm.json", "r01_pmc_decode_gemm.json"):
+    for name in ("r03_pmc_decode_gemm.json", "r02_pmc_decode_gemm.json", "r01_pmc_decode_gemm.json"):
         try:
             d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)))
             return round(d["traffic_bytes"] / d["algorithmic_bytes"], 3)
@@ -261,8 +261,10 @@ def llama_decode_leg(B, n_new):
             "ms_per_step": round(dt / steps * 1e3, 3), "prefill_ms": round(t_prefill * 1e3, 2), "prompt_len": T0,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_step": bytes_step,
-                         # PMC (profiles/r02_pmc_decode_gemm.json): the QKV weight-streaming launch moves 103.7 MB for 101.7 MB
-                         "traffic_over_algorithmic_qkv_gemm": _decode_traffic_ratio()}}
+                         # PMC (profiles/r0x_pmc_decode_gemm.json, NOT measured in this run): bytes past the L2s of the q/k/v
+                         # weight-streaming launch over its algorithmic bytes
+                         "traffic_over_algorithmic_qkv_gemm": _decode_traffic_ratio()},
+            "kernels": "gemm_skinny_sk_kernel (balanced split-K; uncut q/k/v, o, down; cut gate/up, lm_head), attn_decode_rope_kernel<keys early>"}
 
 
 def llama14b_prefill_leg(B=8, T=649):

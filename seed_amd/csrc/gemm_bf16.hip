@@ -107,7 +107,16 @@ SEEDMI_DEVINL void glds16(const bf16_t* gptr, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-
+// The same 16-byte-per-lane LDS-DMA request as a BUFFER load (buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds): the lane's byte offset
+// inside the matrix sits in ONE VGPR for the whole tile, the K advance in the scalar offset - a request costs no VALU instruction.  The
+// flat form above costs v_add_u32 + v_lshl_add_u64 per request (hipcc does not split a flat LDS-DMA address into SGPR base + VGPR offset):
+// 24 of the 48 VALU instructions of two K-tiles of the 256x256 kernel, each of which takes the SIMD's VALU/MFMA issue port from the partner
+// wave's MFMA stream for ~4 cycles.  Destination semantics are those of global_load_lds_dwordx4 (M0 base + 16 * lane, bases above 64 KiB
+// included): tools/probes/buffer_lds_probe.hip.
+SEEDMI_DEVINL void glds16_buf(const __amdgpu_buffer_rsrc_t rsrc, uint32_t lane_byte_off, uint32_t uniform_byte_off, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)lane_byte_off,
+                                             (int)uniform_byte_off, 0, 0);
+}
 
 // ---- nn.GELU() on the half fc1 output as a bf16 -> bf16 table (tools/gen_gelu_lut.py): 5120 entries for 2^-16 <= |x| < 16, held
 // in LDS behind the operand ring.  Per value: one rounding to bf16 (the reference's half fc1 output), ~6 integer VALU and one
@@ -836,6 +845,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // the P4 MFMAs (two separate K loops made hipcc spill ~125 registers per lane into both of them)
     constexpr bool RAGBR = (SCHED & 256) != 0;
     constexpr bool RAGSPLIT = (SCHED & 128) != 0 || RAGBR;
+    // bit 9 (A/B only): LDS-DMA requests in the FLAT form of rounds 1-2 (a 64-bit lane address per request: v_add_u32 + v_lshl_add_u64 each)
+    // instead of the buffer form (lane byte offset in one VGPR per tile, K advance in the scalar offset: no VALU per request)
+    constexpr bool FLATDMA = (SCHED & 512) != 0;
     bool tile_ragged = false;
     static_assert(!TWOPH || (SCHED & 14) == 0, "the two-phase schedule has its own request placement");
     static_assert(!(TWOPH && RAGSPLIT), "the ragged-tile split lives in the four-phase K-tile body");
@@ -887,7 +899,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     next_seg(s_tile, s_kb, s_ke);
 
     int m0 = 0, n0 = 0;
-    uint32_t offA[2][2], offW[2][2];                    // element offsets (< 2^31, checked at the entry point): 32-bit, zero-extended
+    uint32_t offA[2][2], offW[2][2];                    // BYTE offsets of this lane's requests inside A / W (elements < 2^31, checked at the entry point)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, -1, 0x00020000);      // (raw: no stride, 4 GiB range)
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, -1, 0x00020000);
     // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
     auto set_tile = [&](int t) {
         const int gsize = p.group_m * p.tiles_n;
@@ -906,8 +920,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 // TWOPH: a wave's A piece j is 8 rows of the mh0 (j = 0) / mh1 (j = 1) half of the half-tile: rows 64 j + 8 w + ..
                 const int rowA = TWOPH ? 128 * h + 64 * j + 8 * wave + (ln >> 3) : row;
                 const int cs = ln & 7;
-                offA[h][j] = (uint32_t)min(m0 + rowA, p.M - 1) * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(rowA));
-                offW[h][j] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldw + 8u * (uint32_t)(cs ^ swzW(row));
+                offA[h][j] = 2u * ((uint32_t)min(m0 + rowA, p.M - 1) * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(rowA)));
+                offW[h][j] = 2u * ((uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldw + 8u * (uint32_t)(cs ^ swzW(row)));
             }
     };
     // ---- fragment read bases (byte offsets inside a K-tile buffer); tile index adds an immediate
@@ -921,25 +935,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     int tile_rdA = rdA0, tile_rdW = rdW0;
 
     f32x4 acc[8][4];
+    // one 16-byte-per-lane request of A / W: lane byte offset `off` (set_tile), K origin k0 (elements), LDS destination of the wave
+    auto dmaA = [&](uint32_t off, int k0, char* dst) {
+        if (FLATDMA) glds16(p.A + ((off >> 1) + (uint32_t)k0), dst);
+        else glds16_buf(rsA, off, 2u * (uint32_t)k0, dst);
+    };
+    auto dmaW = [&](uint32_t off, int k0, char* dst) {
+        if (FLATDMA) glds16(p.W + ((off >> 1) + (uint32_t)k0), dst);
+        else glds16_buf(rsW, off, 2u * (uint32_t)k0, dst);
+    };
     auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
         char* base = smem + (kt & 1) * KT_BYTES + (TWOPH ? wave * 1024 : wave * 2048);
         const int k0 = kt * BK;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES + (TWOPH ? j * 8192 : j * 1024));
+            for (int j = 0; j < 2; ++j) dmaA(offA[h][j], k0, base + h * HALF_BYTES + (TWOPH ? j * 8192 : j * 1024));
     };
     auto stageA_rows = [&](int kt, int j) {  // TWOPH: this wave's mh0 (j = 0) or mh1 (j = 1) piece of both A half-tiles
         char* base = smem + (kt & 1) * KT_BYTES + wave * 1024 + j * 8192;
         const int k0 = kt * BK;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES);
+        for (int h = 0; h < 2; ++h) dmaA(offA[h][j], k0, base + h * HALF_BYTES);
     };
     auto stageA_half = [&](int kt, int h) {  // one A half-tile of K-tile kt (ASPLIT)
         char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
         const int k0 = kt * BK;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(p.A + (offA[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
+        for (int j = 0; j < 2; ++j) dmaA(offA[h][j], k0, base + h * HALF_BYTES + j * 1024);
     };
     auto stageW = [&](int kt) {
         char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
@@ -947,14 +970,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(p.W + (offW[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
+            for (int j = 0; j < 2; ++j) dmaW(offW[h][j], k0, base + h * HALF_BYTES + j * 1024);
     };
 
     auto stageW_piece = [&](int kt, int j) {   // piece j (8 rows) of both W half-tiles of K-tile kt (WSPLIT): j = 0 nh0 rows, j = 1 nh1 rows
         char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
         const int k0 = kt * BK;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) glds16(p.W + (offW[h][j] + (uint32_t)k0), base + h * HALF_BYTES + j * 1024);
+        for (int h = 0; h < 2; ++h) dmaW(offW[h][j], k0, base + h * HALF_BYTES + j * 1024);
     };
     // prologue loads of a segment: its first K-tile (A and W) and, already in flight behind it, W of the second
     auto issue_prologue = [&](int kb, int ke) {
@@ -1623,6 +1646,8 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
             case 63: return launch_gemm256_sched<EPI, LNF, 63>(p, stream, sk_ws, sk_ws_bytes);
             case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);
             case 287: return launch_gemm256_sched<EPI, LNF, 287>(p, stream, sk_ws, sk_ws_bytes);     // ragged n-tile re-divided: -4 % on EVERY tile
+            case 543: return launch_gemm256_sched<EPI, LNF, 543>(p, stream, sk_ws, sk_ws_bytes);     // schedule 31 with the flat LDS-DMA requests of rounds 1-2
+            case 512: return launch_gemm256_sched<EPI, LNF, 512>(p, stream, sk_ws, sk_ws_bytes);     // schedule 0 with them
 #endif
 #endif
             default: break;
@@ -1688,7 +1713,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 511) {      // (-1 = the default; values without a compiled variant run schedule 0)
+    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 1023) {      // (-1 = the default; values without a compiled variant run schedule 0)
         if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
         return SEEDMI_OK;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Launch the decode GEMM a few times on one shape over distinct weight copies (for rocprofv3 --pmc passes):
-skinny_one.py <N> <K> [M]   (fragment-major weights and activations, folded RMSNorm as in the decode chain)"""
+skinny_one.py <N> <K> [M] [swiglu]   (fragment-major weights and activations, folded RMSNorm, the split-K kernel's workspace: the launch
+the decode chain issues; "swiglu" = the gate/up form with the fragment-major output)"""
 import os
 import sys
 
@@ -21,10 +22,13 @@ for _ in range(4):                                         # > 256 MiB in rotati
     Wps.append(Wp)
     del W
 xp = torch.randn(((M + 15) // 16) * 16 * K, device="cuda", generator=g).bfloat16()
-C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+swiglu = len(sys.argv) > 4 and sys.argv[4] == "swiglu"
+C = torch.zeros(((M + 15) // 16) * 16, N, device="cuda", dtype=torch.bfloat16)
+ws = torch.zeros(lib.seedmi_gemm_skinny_workspace_bytes(), dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
 for _ in range(3):
     for Wp in Wps:
-        L.check(lib.seedmi_gemm_skinny_norm_bf16(M, N, K, L.ptr(xp), 1, L.ptr(Wp), 1e-6, None, 0, L.EPI_NONE, L.ptr(C), N, 0, None,
-                                                 L.stream_ptr()), "skinny")
+        L.check(lib.seedmi_gemm_skinny_norm_ws_bf16(M, N, K, L.ptr(xp), 1, L.ptr(Wp), 1e-6, None, 0, L.EPI_SWIGLU if swiglu else L.EPI_NONE,
+                                                    L.ptr(C), N // 2 if swiglu else N, 1 if swiglu else 0, None, L.ptr(ws), ws.numel(),
+                                                    L.stream_ptr()), "skinny")
 torch.cuda.synchronize()
