@@ -60,8 +60,8 @@ int seedmi_check_device(void);
  * "gemm_sched" (schedule of the 256x256 kernel for the ViT epilogues: -1 = default (31), 0 = the round-2 schedule; bit-identical results),
  * "tokenize_tile_stats" (0|1: LayerNorm statistics by 256-column tile, finalized inside the consuming GEMM instead of by
  * seedmi_layernorm_stats_finalize launches; large batches only),
- * "skinny_nt" / "skinny_waves" / "skinny_rows"
- * (decode GEMM), "skinny_splitk" (which kernel seedmi_gemm_skinny_norm_ws_bf16 runs: 0 = the one-tile-per-workgroup kernel | 1 = the split-K kernel, uncut where the shape divides into whole tiles per workgroup: the default | 2 = the split-K kernel, always cut | 3 = the split-K kernel only where the one-tile form would leave its last round of workgroups under 95 % full), "decode_fused" (0|1 RoPE + append inside decode attention), "decode_attn_early" (fused decode attention: 0 = cached rows requested after the rotation | 1 = first batch of key rows requested ahead of it: the default | 2 = key and value rows; same bits), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
+ * "skinny_waves" / "skinny_rows"
+ * (decode GEMM; "skinny_nt" = 0, temporal weight loads, exists in the devtools build only), "skinny_splitk" (which kernel seedmi_gemm_skinny_norm_ws_bf16 runs: 0 = the one-tile-per-workgroup kernel | 1 = the split-K kernel, uncut where the shape divides into whole tiles per workgroup: the default | 2 = the split-K kernel, always cut | 3 = the split-K kernel only where the one-tile form would leave its last round of workgroups under 95 % full), "decode_fused" (0|1 RoPE + append inside decode attention), "decode_attn_early" (fused decode attention: 0 = cached rows requested after the rotation | 1 = first batch of key rows requested ahead of it: the default | 2 = key and value rows; same bits), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
  * (attention kernel selection; attn_vit: 0 off | 1 twelve-wave ViT kernel | 2 sixteen-wave ViT kernel for 257 tokens).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
 int seedmi_set_option(const char* key, int value);

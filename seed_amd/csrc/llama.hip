@@ -316,9 +316,13 @@ template <int EPI, bool PACKED>
 int launch_skinny(const SkinnyParams& p, hipStream_t s) {
     // 8-way K split when each slice still holds at least two 128-deep batches, else 4-way
     const bool w8 = g_skinny_nw == 8 || (g_skinny_nw == 0 && (p.K % 256) == 0 && p.K >= 2048);
-    if (w8 && (p.K % 256) == 0)
-        return g_skinny_nt ? launch_skinny_nw<EPI, 8, true, PACKED>(p, s) : launch_skinny_nw<EPI, 8, false, PACKED>(p, s);
-    return g_skinny_nt ? launch_skinny_nw<EPI, 4, true, PACKED>(p, s) : launch_skinny_nw<EPI, 4, false, PACKED>(p, s);
+    // (the temporal-load forms - seedmi_set_option("skinny_nt", 0), an A/B switch of round 1 - exist in the devtools build only: they were
+    // half of this file's 288 gemm_skinny_kernel instantiations and of its compile time)
+#ifdef SEEDMI_DEVTOOLS
+    if (!g_skinny_nt) return (w8 && (p.K % 256) == 0) ? launch_skinny_nw<EPI, 8, false, PACKED>(p, s) : launch_skinny_nw<EPI, 4, false, PACKED>(p, s);
+#endif
+    if (w8 && (p.K % 256) == 0) return launch_skinny_nw<EPI, 8, true, PACKED>(p, s);
+    return launch_skinny_nw<EPI, 4, true, PACKED>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------ skinny GEMM, balanced split-K form
@@ -1453,7 +1457,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tiled_kernel(const bf16_t
 }  // namespace
 
 int seedmi_llama_set_option(const char* key, int value) {
+#ifdef SEEDMI_DEVTOOLS
     if (!strcmp(key, "skinny_nt") && (value == 0 || value == 1)) { g_skinny_nt = value; return SEEDMI_OK; }
+#else
+    if (!strcmp(key, "skinny_nt") && value == 1) return SEEDMI_OK;                     // (0 = temporal loads: devtools build only)
+#endif
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_splitk") && (value >= 0 && value <= 3)) { g_skinny_sk = value; return SEEDMI_OK; }
