@@ -767,6 +767,12 @@ constexpr int SEG_BYTES = MAX_SEGS * 3 * 4;
 constexpr int SCRATCH_BYTES = 8 * 256;            // one 256-byte LDS-DMA landing row per wave (residual prefetch touches)
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;          // 64 KiB per K-tile
+// The 256x256 kernel's operand ring (two K-tiles): [A slot 0 | A slot 1 | W slot 0 | W slot 1], 32 KiB each.  A slot is 32 KiB from its
+// twin, so with the slot known at compile time (the K loop is unrolled by two and segments start on even K-tiles) a fragment read is
+// ds_read_b128 v_base offset:(slot * 32768 + piece) - the 16-bit offset field holds it, and the per-K-tile v_add_u32 of a slot base to
+// each of the four lane bases (A / W x k-step 0 / 1: the last VALU instructions of the K loop's LOAD sections) disappears.
+constexpr int RING_SLOT = 2 * HALF_BYTES;         // slot stride inside the A and inside the W region
+constexpr int RING_W = 4 * HALF_BYTES;            // the W region starts behind both A slots
 
 #define SEEDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -787,8 +793,10 @@ SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid
         n_dp = max(n_x / G - 2, 0);                 // whole data-parallel rounds
         sk_tile0 = cs + n_dp * G;
         const int I = (n_x - n_dp * G) * nk;
-        sk_it = (int)(((long long)idx * I) / G);
-        sk_hi = (int)(((long long)(idx + 1) * I) / G);
+        // cuts fall on EVEN K-tiles of their tile (the K loop's ring slots are compile-time constants of an unrolled pair that starts even)
+        auto cut = [&](int i) { const int c = (int)(((long long)i * I) / G); return c - ((c % nk) & 1); };
+        sk_it = cut(idx);
+        sk_hi = idx + 1 == G ? I : cut(idx + 1);
     }
     if (n_dp > MAX_SEGS - 5) n_dp = MAX_SEGS - 5;   // (the launcher keeps nt / grid below this)
     for (int j = tid; j < n_dp; j += 512) { segs[3 * j] = cs + idx + j * G; segs[3 * j + 1] = 0; segs[3 * j + 2] = nk; }
@@ -848,6 +856,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // bit 9 (A/B only): LDS-DMA requests in the FLAT form of rounds 1-2 (a 64-bit lane address per request: v_add_u32 + v_lshl_add_u64 each)
     // instead of the buffer form (lane byte offset in one VGPR per tile, K advance in the scalar offset: no VALU per request)
     constexpr bool FLATDMA = (SCHED & 512) != 0;
+    // bit 10 (A/B only): the ring slot of a K-tile always taken from kt & 1 at run time (one v_add_u32 per lane base per K-tile), as before
+    // the ring's slots were laid 32 KiB apart
+    // (not in the BIAS_RESIDUAL variants: at 255 VGPRs the compile-time slots cost 32-56 B of scratch inside the loop)
+    constexpr bool STATIC_SLOT = (SCHED & 1024) == 0 && EPI != EPI_BIAS_RESIDUAL;
     bool tile_ragged = false;
     static_assert(!TWOPH || (SCHED & 14) == 0, "the two-phase schedule has its own request placement");
     static_assert(!(TWOPH && RAGSPLIT), "the ragged-tile split lives in the four-phase K-tile body");
@@ -929,7 +941,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     //   W: row = 64*wn + 16*(li>>2) + 4*ni + (li&3) inside the 256-row tile, half wn>>1 (swizzle independent of ni)
     const int rowW0 = 64 * wn + 16 * (li >> 2) + (li & 3);
     const int rdA0 = wm * HALF_BYTES + li * 128 + ((g ^ swzA(li)) << 4);
-    const int rdW0 = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((g ^ swzW(rowW0)) << 4);
+    const int rdW0 = (wn >> 1) * HALF_BYTES + (rowW0 & 127) * 128 + ((g ^ swzW(rowW0)) << 4);      // (inside a W slot)
     // (RAGSPLIT: the bases are formed per tile, from a lane id taken there - tile_rdA / tile_rdW below - so that neither K loop's address
     // arithmetic is hoisted over the whole kernel next to the other's)
     int tile_rdA = rdA0, tile_rdW = rdW0;
@@ -945,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         else glds16_buf(rsW, off, 2u * (uint32_t)k0, dst);
     };
     auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
-        char* base = smem + (kt & 1) * KT_BYTES + (TWOPH ? wave * 1024 : wave * 2048);
+        char* base = smem + (kt & 1) * RING_SLOT + (TWOPH ? wave * 1024 : wave * 2048);
         const int k0 = kt * BK;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -953,19 +965,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int j = 0; j < 2; ++j) dmaA(offA[h][j], k0, base + h * HALF_BYTES + (TWOPH ? j * 8192 : j * 1024));
     };
     auto stageA_rows = [&](int kt, int j) {  // TWOPH: this wave's mh0 (j = 0) or mh1 (j = 1) piece of both A half-tiles
-        char* base = smem + (kt & 1) * KT_BYTES + wave * 1024 + j * 8192;
+        char* base = smem + (kt & 1) * RING_SLOT + wave * 1024 + j * 8192;
         const int k0 = kt * BK;
 #pragma unroll
         for (int h = 0; h < 2; ++h) dmaA(offA[h][j], k0, base + h * HALF_BYTES);
     };
     auto stageA_half = [&](int kt, int h) {  // one A half-tile of K-tile kt (ASPLIT)
-        char* base = smem + (kt & 1) * KT_BYTES + wave * 2048;
+        char* base = smem + (kt & 1) * RING_SLOT + wave * 2048;
         const int k0 = kt * BK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) dmaA(offA[h][j], k0, base + h * HALF_BYTES + j * 1024);
     };
     auto stageW = [&](int kt) {
-        char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
+        char* base = smem + RING_W + (kt & 1) * RING_SLOT + wave * 2048;
         const int k0 = kt * BK;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -974,7 +986,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     };
 
     auto stageW_piece = [&](int kt, int j) {   // piece j (8 rows) of both W half-tiles of K-tile kt (WSPLIT): j = 0 nh0 rows, j = 1 nh1 rows
-        char* base = smem + (kt & 1) * KT_BYTES + 2 * HALF_BYTES + wave * 2048;
+        char* base = smem + RING_W + (kt & 1) * RING_SLOT + wave * 2048;
         const int k0 = kt * BK;
 #pragma unroll
         for (int h = 0; h < 2; ++h) dmaW(offW[h][j], k0, base + h * HALF_BYTES + j * 1024);
@@ -1053,15 +1065,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
     // ---- one K-tile, four phases.  fx holds / receives W(nh0), fy W(nh1).  WPRE: on entry fx already holds this K-tile's W(nh0) (read in the
     //      previous K-tile's P4 or ahead of the loop); in P4 fy - dead after P3 - receives W(nh0) of K-tile kt + 1, so the caller swaps roles.
-    auto ktile = [&](auto rg_tag, const int kt, const int ke, bf16x8 (&fx)[4], bf16x8 (&fy)[4], const bool stamp) {
+    auto ktile = [&](auto rg_tag, auto slot_tag, const int kt, const int ke, bf16x8 (&fx)[4], bf16x8 (&fy)[4], const bool stamp) {
         constexpr bool RGT = decltype(rg_tag)::value;   // ragged-tile split: this wave's 64 rows x 64 columns, phases P1 / P2 only
         const bool RG = RGT || (RAGBR && tile_ragged);  // (RAGBR: decided per tile at run time)
-        const char* sb = smem + (kt & 1) * KT_BYTES;
+        constexpr int SLOT = decltype(slot_tag)::value; // 0 / 1: the ring slot of K-tile kt, known at compile time; -1: kt & 1
+        const int slot = SLOT >= 0 ? SLOT : (kt & 1);
         const int bA = RAGSPLIT ? tile_rdA : rdA0, bW = RAGSPLIT ? tile_rdW : rdW0;
-        const char* pa0 = sb + bA;                      // k-step 0
-        const char* pa1 = sb + (bA ^ 64);               // k-step 1
-        const char* pw0 = sb + bW;
-        const char* pw1 = sb + (bW ^ 64);
+        const char* pa0 = smem + bA + slot * RING_SLOT;                      // k-step 0
+        const char* pa1 = smem + (bA ^ 64) + slot * RING_SLOT;               // k-step 1
+        const char* pw0 = smem + bW + (RING_W + slot * RING_SLOT);
+        const char* pw1 = smem + (bW ^ 64) + (RING_W + slot * RING_SLOT);
         (void)stamp;
         if (stamp) GSTAMP(16);
 
@@ -1190,9 +1203,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             if (kt + 2 < ke) stageW(kt + 2);               // W slots of this parity were last read in P2
         }
         if (WPRE && kt + 1 < ke) {                     // next K-tile's W(nh0): other parity, retired by P3's counted wait + two barriers
-            const char* sn = smem + ((kt + 1) & 1) * KT_BYTES;
-            const char* qw0 = sn + bW;
-            const char* qw1 = sn + (bW ^ 64);
+            const char* qw0 = smem + bW + (RING_W + (slot ^ 1) * RING_SLOT);
+            const char* qw1 = smem + (bW ^ 64) + (RING_W + (slot ^ 1) * RING_SLOT);
 #pragma unroll
             for (int t = 0; t < 2; ++t) { fy[t] = *(const bf16x8*)(qw0 + t * 512); fy[2 + t] = *(const bf16x8*)(qw1 + t * 512); }
         }
@@ -1256,11 +1268,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
     // ---- TWOPH: one K-tile in two phases of 32 MFMAs (see the SCHED notes above the kernel)
     auto ktile2 = [&](const int kt, const int kb, const int ke) {
-        const char* sb = smem + (kt & 1) * KT_BYTES;
+        const char* sb = smem + (kt & 1) * RING_SLOT;
         const char* pa0 = sb + rdA0;                    // k-step 0
         const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
-        const char* pw0 = sb + rdW0;
-        const char* pw1 = sb + (rdW0 ^ 64);
+        const char* pw0 = sb + RING_W + rdW0;
+        const char* pw1 = sb + RING_W + (rdW0 ^ 64);
         // ================= phase a: rows mh0 x (nh0, nh1) =================
         // A-mh1(kt), requested in phase a of kt-1, is read in phase b: everything but the six requests of phase b of kt-1 must have landed
         // (the segment's first K-tile came with the prologue and was waited for at the tile's opening)
@@ -1397,29 +1409,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const bool ragged = RAGSPLIT && (p.N - en0) <= 128 && !p.stats_by_tile;
     using rg_no = std::false_type;
     using rg_yes = std::true_type;
+    using slot_dyn = std::integral_constant<int, -1>;
     if (RAGSPLIT) {
         // this tile's fragment read bases: ordinary = A rows 16 mi + li of half-tile wm, W rows of column group wn; ragged split = A rows
         // 64 (wn >> 1) + 16 mi + li, W rows of column group wn & 1 (W half-tile 0)
         const int kl = fresh_lane(), kli = kl & 15, kg = kl >> 4;
         const int wcol = ragged ? (wn & 1) : wn;
         const int rw = 64 * wcol + 16 * (kli >> 2) + (kli & 3);
-        tile_rdW = 2 * HALF_BYTES + (wcol >> 1) * HALF_BYTES + (rw & 127) * 128 + ((kg ^ swzW(rw)) << 4);
+        tile_rdW = (wcol >> 1) * HALF_BYTES + (rw & 127) * 128 + ((kg ^ swzW(rw)) << 4);
         tile_rdA = wm * HALF_BYTES + (ragged ? (wn >> 1) * (64 * 128) : 0) + kli * 128 + ((kg ^ swzA(kli)) << 4);
     }
     tile_ragged = ragged;
     if (ragged && !RAGBR) {
         if (WPRE) {
-            const char* sb = smem + (kb & 1) * KT_BYTES;
+            const char* sb = smem + RING_W + (kb & 1) * RING_SLOT;
 #pragma unroll
             for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(sb + tile_rdW + t * 512); fw0[2 + t] = *(const bf16x8*)(sb + (tile_rdW ^ 64) + t * 512); }
             int kt = kb;
             for (; kt + 1 < ke; kt += 2) {
-                ktile(rg_yes(), kt, ke, fw0, fw1, false);
-                ktile(rg_yes(), kt + 1, ke, fw1, fw0, false);
+                ktile(rg_yes(), slot_dyn(), kt, ke, fw0, fw1, false);
+                ktile(rg_yes(), slot_dyn(), kt + 1, ke, fw1, fw0, false);
             }
-            if (kt < ke) ktile(rg_yes(), kt, ke, fw0, fw1, false);
+            if (kt < ke) ktile(rg_yes(), slot_dyn(), kt, ke, fw0, fw1, false);
         } else {
-            for (int kt = kb; kt < ke; ++kt) ktile(rg_yes(), kt, ke, fw0, fw1, false);
+            for (int kt = kb; kt < ke; ++kt) ktile(rg_yes(), slot_dyn(), kt, ke, fw0, fw1, false);
         }
     } else if ((live || ragged) && TWOPH) {
         for (int kt = kb; kt < ke; ++kt) ktile2(kt, kb, ke);
@@ -1446,18 +1459,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     } else if (live || ragged) {
         if (WPRE) {
             // W(nh0) of the segment's first K-tile (every later one is read in the P4 in front of it); the two fragment sets swap roles per K-tile
-            const char* sb = smem + (kb & 1) * KT_BYTES;
+            const char* sb = smem + RING_W + (kb & 1) * RING_SLOT;
             const int bW = RAGSPLIT ? tile_rdW : rdW0;
 #pragma unroll
             for (int t = 0; t < 2; ++t) { fw0[t] = *(const bf16x8*)(sb + bW + t * 512); fw0[2 + t] = *(const bf16x8*)(sb + (bW ^ 64) + t * 512); }
             int kt = kb;
+            // segments start on even K-tiles (build_segments): the ring slot of each K-tile of the unrolled pair is a compile-time constant and
+            // travels in the fragment reads' offset field.  (ONE loop: a run-time-slot twin beside it made hipcc spill ~480 B per lane.)
+            using slot_a = std::integral_constant<int, STATIC_SLOT ? 0 : -1>;
+            using slot_b = std::integral_constant<int, STATIC_SLOT ? 1 : -1>;
             for (; kt + 1 < ke; kt += 2) {
-                ktile(rg_no(), kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
-                ktile(rg_no(), kt + 1, ke, fw1, fw0, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
+                ktile(rg_no(), slot_a(), kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
+                ktile(rg_no(), slot_b(), kt + 1, ke, fw1, fw0, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
             }
-            if (kt < ke) ktile(rg_no(), kt, ke, fw0, fw1, false);
+            if (kt < ke) ktile(rg_no(), slot_a(), kt, ke, fw0, fw1, false);
         } else {
-            for (int kt = kb; kt < ke; ++kt) ktile(rg_no(), kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
+            for (int kt = kb; kt < ke; ++kt) ktile(rg_no(), slot_dyn(), kt, ke, fw0, fw1, kt - kb >= 4 && kt - kb < 16 && ((kt - kb) & 1) == 0);
         }
     } else {
         for (int kt = kb; kt < ke; ++kt) {
@@ -1648,6 +1665,7 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
             case 287: return launch_gemm256_sched<EPI, LNF, 287>(p, stream, sk_ws, sk_ws_bytes);     // ragged n-tile re-divided: -4 % on EVERY tile
             case 543: return launch_gemm256_sched<EPI, LNF, 543>(p, stream, sk_ws, sk_ws_bytes);     // schedule 31 with the flat LDS-DMA requests of rounds 1-2
             case 512: return launch_gemm256_sched<EPI, LNF, 512>(p, stream, sk_ws, sk_ws_bytes);     // schedule 0 with them
+            case 1055: return launch_gemm256_sched<EPI, LNF, 1055>(p, stream, sk_ws, sk_ws_bytes);   // schedule 31 with run-time ring slots
 #endif
 #endif
             default: break;
@@ -1713,7 +1731,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 1023) {      // (-1 = the default; values without a compiled variant run schedule 0)
+    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 2047) {      // (-1 = the default; values without a compiled variant run schedule 0)
         if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
         return SEEDMI_OK;
