@@ -357,6 +357,11 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
         __syncthreads();
     }
 
+    // (Round 3, measured and NOT adopted - profiles/r03_call21_attention_buffer_staging.log, r03_call22_attention_stride3_staging.log: these
+    // requests in the buffer form of gemm_bf16.hip - lane offset formed once per call and shared by K and Q - 152.7 vs 152.2 us at B = 128;
+    // a wave's pieces dealt as p0, p0 + 3, p0 + 6 (the same chunk column 16 rows further down: ONE lane offset per call, the rest scalar)
+    // 160.7 us: the ~90 VALU instructions saved per item cost more than they bring once a wave's requests sit 3 KiB apart instead of
+    // adjacent to its neighbours'.  Lane offsets kept in registers across the item: 240 B of scratch in this 128-register kernel.)
     auto stage = [&](const bf16_t* base, int ld, bf16_t* dst, int item, bool skip_pad = false) {
         const int b = item / p.heads, h = item - b * p.heads;
         const bf16_t* src = base + (size_t)b * n * ld + h * VHD;
