@@ -341,6 +341,13 @@ int launch_skinny(const SkinnyParams& p, hipStream_t s) {
 // (the flag area is all-zero between launches: graph replays need no epoch).  All workgroups must be resident (grid <= CUs x
 // occupancy, checked by the launcher); waits are bounded and a lost partner is recorded in the sticky error word, like gemm256's stream-K.
 // Logical workgroup order runs XCD by XCD (q = (id % 8) * (G / 8) + id / 8), so an image is produced and consumed on one L2.
+#ifndef SEEDMI_SK_NT
+// weight loads of the split-K kernel: 1 = non-temporal (`nt`), 0 = plain (A/B builds: python -m seed_amd.build --variant sknt0 -DSEEDMI_SK_NT=0).
+// Measured (profiles/r03_call23_decode_weight_load_hint.log): nt 20.3 / 10.5 / 33.8-36.8 / 22.9 us for q/k/v, o, gate/up, down against
+// 23.3 / 10.7 / 37.5-39.4 / 24.2 plain, 8B step 3.39-3.49 vs 3.64-3.65 ms - plain weight lines push the activations out of the L2s.
+// (A bare stream of 64-200 MiB is the other way round, plain 5-12 % faster: tools/probes/cache_retention_probe.hip - nothing there to keep.)
+#define SEEDMI_SK_NT 1
+#endif
 struct SkinnySk {
     float* slabs;                // [G][SK2_SLAB_FLOATS]
     unsigned* flags;             // [G] + error word at SK2_FLAG_WORDS - 1
@@ -439,7 +446,11 @@ __global__ __launch_bounds__(512, WGS == 2 ? 4 : 1) void gemm_skinny_sk_kernel(c
         for (int u2 = 0; u2 < U; ++u2) {
             const int kk = min(U * b + u2, n - 1) * 512 + loff;          // clamped: out-of-range steps are skipped below
 #pragma unroll
+#if SEEDMI_SK_NT
             for (int r = 0; r < R; ++r) wf[u2][r] = __builtin_nontemporal_load((const bf16x8*)(wp[r] + kk));
+#else
+            for (int r = 0; r < R; ++r) wf[u2][r] = *(const bf16x8*)(wp[r] + kk);
+#endif
 #pragma unroll
             for (int t = 0; t < MT; ++t) af[u2][t] = *(const bf16x8*)(ap[t] + kk);
         }
