@@ -53,7 +53,7 @@ std::atomic<int> g_gemm_variant{0};  // "gemm": 0 = auto, 128 / 256 = force a ke
 // "gemm_sched": schedule variant of the 256x256 kernel (bits: see gemm256_kernel) for the three ViT epilogues.  31 = every measured gain of
 // round 3 (epilogue-side wait, W pre-read, two LDS-DMA requests per phase with counted waits, early residual requests): bit-identical to
 // schedule 0, +3..5 % per GEMM, +3.4 % end to end (profiles/r03_gemm_sched_ab_call*.json).  0 = the round-2 schedule.
-constexpr int GEMM_SCHED_DEFAULT = 31;
+constexpr int GEMM_SCHED_DEFAULT = 81;           // two-phase K-tile + counted waits across tile boundaries + early residual rows (see gemm256_kernel)
 std::atomic<int> g_gemm_sched{GEMM_SCHED_DEFAULT};
 #ifdef SEEDMI_DEVTOOLS
 unsigned long long* g_gemm_dbg = nullptr;   // seedmi_gemm_phase_timing: device buffer for the phase clock stamps
@@ -1267,12 +1267,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     };
 
     // ---- TWOPH: one K-tile in two phases of 32 MFMAs (see the SCHED notes above the kernel)
-    auto ktile2 = [&](const int kt, const int kb, const int ke) {
-        const char* sb = smem + (kt & 1) * RING_SLOT;
-        const char* pa0 = sb + rdA0;                    // k-step 0
-        const char* pa1 = sb + (rdA0 ^ 64);             // k-step 1
-        const char* pw0 = sb + RING_W + rdW0;
-        const char* pw1 = sb + RING_W + (rdW0 ^ 64);
+    auto ktile2 = [&](auto slot_tag, const int kt, const int kb, const int ke) {
+        constexpr int SLOT = decltype(slot_tag)::value; // 0 / 1: the ring slot of K-tile kt, known at compile time; -1: kt & 1
+        const int slot = SLOT >= 0 ? SLOT : (kt & 1);
+        const char* pa0 = smem + rdA0 + slot * RING_SLOT;                    // k-step 0
+        const char* pa1 = smem + (rdA0 ^ 64) + slot * RING_SLOT;             // k-step 1
+        const char* pw0 = smem + rdW0 + (RING_W + slot * RING_SLOT);
+        const char* pw1 = smem + (rdW0 ^ 64) + (RING_W + slot * RING_SLOT);
         // ================= phase a: rows mh0 x (nh0, nh1) =================
         // A-mh1(kt), requested in phase a of kt-1, is read in phase b: everything but the six requests of phase b of kt-1 must have landed
         // (the segment's first K-tile came with the prologue and was waited for at the tile's opening)
@@ -1435,7 +1436,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int kt = kb; kt < ke; ++kt) ktile(rg_yes(), slot_dyn(), kt, ke, fw0, fw1, false);
         }
     } else if ((live || ragged) && TWOPH) {
-        for (int kt = kb; kt < ke; ++kt) ktile2(kt, kb, ke);
+        // (a pair-unrolled form with compile-time ring slots - as in the four-phase loop - costs 64 B of scratch here: run-time slots)
+        for (int kt = kb; kt < ke; ++kt) ktile2(slot_dyn(), kt, kb, ke);
     } else if (!live && TWOPH) {
         // same requests, waits and barriers as ktile2, no fragment reads, no MFMA
         for (int kt = kb; kt < ke; ++kt) {
@@ -1656,12 +1658,15 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
 #ifdef SEEDMI_SCHED_ONLY                               // (register-pressure experiments: one variant, short compile)
             case SEEDMI_SCHED_ONLY: return launch_gemm256_sched<EPI, LNF, SEEDMI_SCHED_ONLY>(p, stream, sk_ws, sk_ws_bytes);
 #else
-            case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);
-#ifdef SEEDMI_DEVTOOLS                                 // measured steps and the rejected two-phase schedule (tools/gemm_sched_ab.py)
+            case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);      // two-phase K-tile: the default
+            case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);      // four-phase K-tile (the default before the buffer-form requests)
+#ifdef SEEDMI_DEVTOOLS                                 // measured steps (tools/gemm_sched_ab.py)
             case 7: return launch_gemm256_sched<EPI, LNF, 7>(p, stream, sk_ws, sk_ws_bytes);
             case 15: return launch_gemm256_sched<EPI, LNF, 15>(p, stream, sk_ws, sk_ws_bytes);
             case 63: return launch_gemm256_sched<EPI, LNF, 63>(p, stream, sk_ws, sk_ws_bytes);
-            case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);
+            case 593: return launch_gemm256_sched<EPI, LNF, 593>(p, stream, sk_ws, sk_ws_bytes);     // two-phase K-tile with the flat requests of rounds 1-2
+            case 113: return launch_gemm256_sched<EPI, LNF, 113>(p, stream, sk_ws, sk_ws_bytes);     // two-phase K-tile + static wave priority
+            case 65: return launch_gemm256_sched<EPI, LNF, 65>(p, stream, sk_ws, sk_ws_bytes);       // two-phase K-tile without the early residual rows
             case 287: return launch_gemm256_sched<EPI, LNF, 287>(p, stream, sk_ws, sk_ws_bytes);     // ragged n-tile re-divided: -4 % on EVERY tile
             case 543: return launch_gemm256_sched<EPI, LNF, 543>(p, stream, sk_ws, sk_ws_bytes);     // schedule 31 with the flat LDS-DMA requests of rounds 1-2
             case 512: return launch_gemm256_sched<EPI, LNF, 512>(p, stream, sk_ws, sk_ws_bytes);     // schedule 0 with them
