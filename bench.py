@@ -119,7 +119,7 @@ def qkv_gemm_roofline(batch):
             traffic = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
             traffic_src = "profiles/" + name + " (rocprofv3 --pmc passes of this launch, tools/pmc_qkv.sh; NOT measured in this run)"
             break
-    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS, LayerNorm fold, schedule 31>, persistent (ViT norm1 + QKV: M=%d K=%d N=%d)" % (M, K, N),
+    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS, LayerNorm fold, schedule 81 (two-phase K-tile)>, persistent (ViT norm1 + QKV: M=%d K=%d N=%d)" % (M, K, N),
             "plain_linear": {"avg_launch_ms": round(plain_avg_ms, 4), "achieved": round(flops / (plain_avg_ms * 1e-3) / 1e12, 1)},
             "with_streamk_tail": {"avg_launch_ms": round(sk_avg_ms, 4), "achieved": round(flops / (sk_avg_ms * 1e-3) / 1e12, 1)},
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

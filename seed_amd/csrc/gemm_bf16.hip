@@ -860,6 +860,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // the ring's slots were laid 32 KiB apart
     // (not in the BIAS_RESIDUAL variants: at 255 VGPRs the compile-time slots cost 32-56 B of scratch inside the loop)
     constexpr bool STATIC_SLOT = (SCHED & 1024) == 0 && EPI != EPI_BIAS_RESIDUAL;
+    // bit 11 (two-phase K-tile): the fragment reads of a phase are waited for BEHIND the phase's barrier instead of in front of it
+    constexpr bool LATEWAIT = (SCHED & 2048) != 0;
     bool tile_ragged = false;
     static_assert(!TWOPH || (SCHED & 14) == 0, "the two-phase schedule has its own request placement");
     static_assert(!(TWOPH && RAGSPLIT), "the ragged-tile split lives in the four-phase K-tile body");
@@ -1288,9 +1290,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
         if (kt + 1 < ke) stageA_rows(kt + 1, 1);        // mh1 rows of the other parity: last read in phase b of kt-1, retired before its barrier
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!LATEWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
+        if (LATEWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the fragments land while the wave waits at the barrier)
         SEEDMI_SCHED_FENCE();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1314,9 +1317,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             stageW(kt + 2);
             stageA_rows(kt + 2, 0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!LATEWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
+        if (LATEWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the fragments land while the wave waits at the barrier)
         SEEDMI_SCHED_FENCE();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1666,6 +1670,7 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
             case 63: return launch_gemm256_sched<EPI, LNF, 63>(p, stream, sk_ws, sk_ws_bytes);
             case 593: return launch_gemm256_sched<EPI, LNF, 593>(p, stream, sk_ws, sk_ws_bytes);     // two-phase K-tile with the flat requests of rounds 1-2
             case 113: return launch_gemm256_sched<EPI, LNF, 113>(p, stream, sk_ws, sk_ws_bytes);     // two-phase K-tile + static wave priority
+            case 2129: return launch_gemm256_sched<EPI, LNF, 2129>(p, stream, sk_ws, sk_ws_bytes);   // two-phase K-tile, fragment waits behind the barriers
             case 65: return launch_gemm256_sched<EPI, LNF, 65>(p, stream, sk_ws, sk_ws_bytes);       // two-phase K-tile without the early residual rows
             case 287: return launch_gemm256_sched<EPI, LNF, 287>(p, stream, sk_ws, sk_ws_bytes);     // ragged n-tile re-divided: -4 % on EVERY tile
             case 543: return launch_gemm256_sched<EPI, LNF, 543>(p, stream, sk_ws, sk_ws_bytes);     // schedule 31 with the flat LDS-DMA requests of rounds 1-2
@@ -1736,7 +1741,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 2047) {      // (-1 = the default; values without a compiled variant run schedule 0)
+    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 4095) {      // (-1 = the default; values without a compiled variant run schedule 0)
         if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
         return SEEDMI_OK;
