@@ -1681,6 +1681,12 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
             default: break;
         }
     }
+    // the other epilogues (plain, SwiGLU, tanh, ReLU: LLaMA prefill, the head MLPs) take the two-phase K-tile too - one variant each
+    if constexpr (!LNF && (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_BIAS_TANH || EPI == EPI_RELU)) {
+#ifndef SEEDMI_SCHED_ONLY
+        if (g_gemm_sched.load() == 81) return launch_gemm256_sched<EPI, LNF, 65>(p, stream, sk_ws, sk_ws_bytes);
+#endif
+    }
     return launch_gemm256_sched<EPI, LNF, 0>(p, stream, sk_ws, sk_ws_bytes);
 }
 
