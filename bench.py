@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
     ap.add_argument("--no-llama", action="store_true", help="skip the SEED-LLaMA-8B decode leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prefill14b", action="store_true", help="also run the SEED-LLaMA-14B prefill leg (config 5; ~1 min extra)")
+    ap.add_argument("--prefill14b", action="store_true", help="(default since round 4; kept so old command lines still parse)")
+    ap.add_argument("--no-prefill14b", action="store_true", help="skip the SEED-LLaMA-14B prefill leg (config 5; ~1 min)")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--decode-batch", type=int, default=32)
     ap.add_argument("--decode-new", type=int, default=128)
@@ -73,7 +74,8 @@ def qkv_gemm_roofline(batch):
     bias = torch.zeros(N, device="cuda").bfloat16()
     Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 
-    # the launch the tokenize path issues for this GEMM: LayerNorm (norm1) folded in - A is the un-normalised residual stream, the
+    # the form in which the tokenize path issues this GEMM (at M = batch * 257, BASELINE's definition; the path itself issues two
+    # half-batch launches on two streams, timed below as run_half): LayerNorm (norm1) folded in - A is the un-normalised residual stream, the
     # row statistics, column sums and folded bias are the fold's operands (seedmi_gemm_bf16_ext; seedmi_tokenize passes no stream-K
     # workspace by default).  The plain nn.Linear launch and the one with the stream-K tail are timed beside it.
     import ctypes
@@ -94,6 +96,14 @@ def qkv_gemm_roofline(batch):
     def run_sk():
         L.check(lib.seedmi_gemm_bf16_ws(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(Cc), N,
                                         0, 0, L.ptr(ws), ws.numel(), L.stream_ptr()), "gemm")
+
+    # seedmi_tokenize splits a batch >= 32 into two sub-batches on two streams (tokenizer.hip), so the launch the timed path issues is
+    # this one at M = (batch / 2) * 257; timed here alone on one stream (in the path two of them overlap)
+    Mh = (batch // 2) * 257
+
+    def run_half():
+        L.check(lib.seedmi_gemm_bf16_ext(Mh, N, K, L.ptr(A), K, L.ptr(W), K, None, None, 0, L.EPI_BIAS, L.ptr(Cc), N, 0, 0,
+                                         ctypes.byref(ext), None, 0, L.stream_ptr()), "gemm ext half")
     # the three launches are timed in alternating blocks after a common warm-up: timed one after the other, whichever came first ran
     # on colder clocks (the first block of a cold chip measured 0.74 ms for a 0.65 ms launch)
     for fn in (run, run_sk, run_plain) * 4:
@@ -106,10 +116,11 @@ def qkv_gemm_roofline(batch):
     med_ms = sorted(m for _, m in acc[run])[1]
     sk_avg_ms = sum(a for a, _ in acc[run_sk]) / 3
     plain_avg_ms = sum(a for a, _ in acc[run_plain]) / 3
+    half_ms = sum(time_kernel_events(run_half, 10, warm=2)[0] for _ in range(3)) / 3
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    for name in ("r03_pmc_qkv_gemm256.json", "r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
+    for name in ("r04_pmc_qkv_gemm256.json", "r03_pmc_qkv_gemm256.json", "r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if batch == 256 and os.path.exists(pmc):
             # bytes past the L2s per launch from rocprofv3 --pmc passes of this same kernel/shape (tools/pmc_qkv.sh: PMC counters
@@ -120,6 +131,9 @@ def qkv_gemm_roofline(batch):
             traffic_src = "profiles/" + name + " (rocprofv3 --pmc passes of this launch, tools/pmc_qkv.sh; NOT measured in this run)"
             break
     return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS, LayerNorm fold, schedule 81 (two-phase K-tile)>, persistent (ViT norm1 + QKV: M=%d K=%d N=%d)" % (M, K, N),
+            "launch": "BASELINE-defined M = batch * 257 = %d launch (the tokenize path issues 2 x M = %d on two streams: in_path_launch)" % (M, Mh),
+            "in_path_launch": {"M": Mh, "avg_launch_ms": round(half_ms, 4), "achieved": round(2.0 * Mh * N * K / (half_ms * 1e-3) / 1e12, 1),
+                               "note": "isolated on one stream; inside seedmi_tokenize two such launches overlap"},
             "plain_linear": {"avg_launch_ms": round(plain_avg_ms, 4), "achieved": round(flops / (plain_avg_ms * 1e-3) / 1e12, 1)},
             "with_streamk_tail": {"avg_launch_ms": round(sk_avg_ms, 4), "achieved": round(flops / (sk_avg_ms * 1e-3) / 1e12, 1)},
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -134,30 +148,31 @@ def measured_ceilings():
     headline fraction keeps as its denominator) and a 16-byte non-temporal stream read of 4 GiB."""
     import ctypes
     from seed_amd import lib as L
-    lib = L.load()
+    from tools import calib                  # libseedcal.so: calibration kernels live outside the product library
+    cal = calib.load()
     scratch = torch.zeros(4, dtype=torch.float32, device="cuda")
     out = {}
     for shape, name in ((0, "mfma_only_16x16x32_tflops"), (1, "mfma_only_32x32x16_tflops")):
         fl = ctypes.c_double(0.0)
 
         def run():
-            L.check(lib.seedmi_bench_mfma_bf16(shape, 20000, 256, L.ptr(scratch), ctypes.byref(fl), L.stream_ptr()), "mfma bench")
+            calib.check(cal.seedcal_mfma_bf16(shape, 20000, 256, L.ptr(scratch), ctypes.byref(fl), L.stream_ptr()), "mfma bench")
         avg_ms, _ = time_kernel_events(run, 5, warm=2)
         out[name] = round(fl.value / (avg_ms * 1e-3) / 1e12, 1)
     buf = torch.empty(4 << 30, dtype=torch.uint8, device="cuda")
     buf.view(torch.int32).fill_(0x01020304)
 
     def rd():
-        L.check(lib.seedmi_bench_stream_read(L.ptr(buf), buf.numel(), 4, L.ptr(scratch), L.stream_ptr()), "stream read")
+        calib.check(cal.seedcal_stream_read(L.ptr(buf), buf.numel(), 4, L.ptr(scratch), L.stream_ptr()), "stream read")
     avg_ms, _ = time_kernel_events(rd, 5, warm=2)
     out["hbm_stream_read_gbps"] = round(buf.numel() / (avg_ms * 1e-3) / 1e9, 1)
-    out["source"] = "measured in this run (seedmi_bench_mfma_bf16, seedmi_bench_stream_read)"
+    out["source"] = "measured in this run (tools/calib: seedcal_mfma_bf16, seedcal_stream_read)"
     return out
 
 
-def _time_reference_modules(n_images, cores):
-    """The reference's OWN modules (models/seed_qformer/*.py under /root/reference, imported through oracle/ref_shims.py) on the
-    same images and weights: only possible where the reference tree exists (the build container), never on the GPU box."""
+def _reference_tokenizer():
+    """The reference's OWN modules (models/seed_qformer/*.py), imported through oracle/ref_shims.py from /root/reference where that tree
+    exists and from the bytecode oracle/build_ref.py compiled into oracle/_ref/ otherwise (that directory travels to the GPU box)."""
     from oracle import ref_shims, make_golden
     from seed_amd import config as C
     from seed_amd.weights import make_tokenizer_state_dict
@@ -165,51 +180,59 @@ def _time_reference_modules(n_images, cores):
     sd = make_tokenizer_state_dict(C.SEED2, seed=0)
     mods = ref_shims.build_reference_tokenizer_modules(ref, C.SEED2)
     make_golden.load_tokenizer_weights(mods, sd)
-    img = torch.randn(n_images, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
     qt = sd["query_tokens"].clone()
-    ref_shims.reference_get_codebook_indices(mods, qt, img[:1])
+    return (lambda img: ref_shims.reference_get_codebook_indices(mods, qt, img)), ref_shims.reference_origin()
+
+
+def _timed(fn, img):
     t0 = time.time()
-    ref_shims.reference_get_codebook_indices(mods, qt, img)
+    fn(img)
     return time.time() - t0
 
 
 def cpu_baseline(n_images):
-    """The CPU path on a bounded sample of the workload, fp32, on the host cores: the reference's own modules when /root/reference
-    is present ("reference"; the oracle port is then timed beside it), otherwise the oracle (a port of those modules)."""
-    from oracle import seed_oracle as O
+    """The CPU path on a bounded sample of the workload, fp32, on THIS node's host cores: the reference's own modules ("reference";
+    the oracle port timed beside it) wherever they can be imported - /root/reference in the build container, oracle/_ref on the GPU
+    box - and the oracle port alone ("port") only if neither exists.  The thread count is not chosen by fiat: two images are timed
+    at 8 / 32 / 64 / all host threads and the fastest setting runs the sample."""
+    from oracle import seed_oracle as O, ref_shims
     from seed_amd import config as C
     from seed_amd.weights import make_tokenizer_state_dict
-    cores = min(os.cpu_count() or 1, 32)       # beyond ~32 threads torch's CPU GEMMs at this size only lose to contention
-    torch.set_num_threads(cores)
-    sd = make_tokenizer_state_dict(C.SEED2, seed=0)
+    ncpu = os.cpu_count() or 1
     img = torch.randn(n_images, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
-    O.get_codebook_indices(sd, img[:1], C.SEED2, "fp32")           # warm-up (thread pool, allocator)
-    t0 = time.time()
-    O.get_codebook_indices(sd, img, C.SEED2, "fp32")
-    dt = time.time() - t0
-    res = {"value": round(n_images / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-           "sample": f"{n_images} images (one batch) of the same synthetic 224x224 workload, fp32 oracle, "
-                     f"torch CPU with {cores} of {os.cpu_count()} host threads, {dt:.1f} s"}
-    if os.path.isdir("/root/reference/models/seed_qformer"):
+    ref_fn, origin, ref_err = None, None, None
+    if ref_shims.reference_available():
         try:
-            dt_ref = _time_reference_modules(n_images, cores)
-            res = {"value": round(n_images / dt_ref, 3), "unit": "images/s", "cores": cores, "kind": "reference",
-                   "sample": f"{n_images} images (one batch), the reference's own modules (fp32, dependency shims only), torch CPU with "
-                             f"{cores} of {os.cpu_count()} host threads, {dt_ref:.1f} s; oracle port on the same sample: "
-                             f"{n_images / dt:.3f} images/s",
-                   "port_value": round(n_images / dt, 3)}
+            ref_fn, origin = _reference_tokenizer()
         except Exception as e:
-            res["reference_error"] = repr(e)[:200]
+            ref_err = repr(e)[:200]
+    sd = make_tokenizer_state_dict(C.SEED2, seed=0)
+    port_fn = lambda x: O.get_codebook_indices(sd, x, C.SEED2, "fp32")      # noqa: E731
+    main_fn = ref_fn or port_fn
+    sweep = {}
+    for th in sorted({t for t in (8, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(th)
+        main_fn(img[:1])                                                  # warm-up (thread pool, allocator)
+        sweep[th] = round(2 / _timed(main_fn, img[:2]), 3)
+    cores = max(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    main_fn(img[:1])
+    dt = _timed(main_fn, img)
+    port_fn(img[:1])
+    dt_port = dt if ref_fn is None else _timed(port_fn, img)
+    if ref_fn is not None:
+        res = {"value": round(n_images / dt, 3), "unit": "images/s", "cores": cores, "kind": "reference",
+               "sample": f"{n_images} images (one batch) of the same synthetic 224x224 workload, the reference's own modules from {origin} "
+                         f"(fp32, dependency shims only), torch CPU with {cores} of {ncpu} host threads (fastest of the sweep), {dt:.1f} s; "
+                         f"oracle port on the same sample: {n_images / dt_port:.3f} images/s",
+               "port_value": round(n_images / dt_port, 3)}
     else:
-        # the reference tree does not travel to the GPU box: next to the live port number, the reference's own modules as they were
-        # timed in the build container (a labelled constant with its core count and date, not a measurement of this run)
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_reference_baseline.json")))
-            res["reference_modules_build_container"] = {"kind": "reference", "value": d["value"], "unit": d["unit"], "cores": d["cores"],
-                                                        "measured": d["measured"], "date": d["date"], "sample": d["sample"],
-                                                        "source": "profiles/r03_cpu_reference_baseline.json (NOT measured in this run)"}
-        except Exception:
-            pass
+        res = {"value": round(n_images / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+               "sample": f"{n_images} images (one batch) of the same synthetic 224x224 workload, fp32 oracle, "
+                         f"torch CPU with {cores} of {ncpu} host threads (fastest of the sweep), {dt:.1f} s"}
+        if ref_err:
+            res["reference_error"] = ref_err
+    res["thread_sweep_images_per_s"] = {str(k): v for k, v in sweep.items()}
     return res
 
 
@@ -251,6 +274,7 @@ def llama_decode_leg(B, n_new):
     replay(n_new - 1)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    eng.decode_status(B)                                           # (outside the timed region: reads the split-K error word)
     assert int(out.min()) >= 0 and int(out.max()) < cfg.vocab
     steps = n_new - 1
     tok_s = B * steps / dt
@@ -392,7 +416,7 @@ def main():
                 extra["llama_decode"] = llama_decode_leg(args.decode_batch, args.decode_new)
             except Exception as e:  # the tokenize line must survive a failure of the secondary leg
                 extra["llama_decode"] = {"error": repr(e)[:300]}
-        if world == 1 and args.prefill14b:
+        if world == 1 and not args.no_prefill14b:
             torch.cuda.empty_cache()
             try:
                 extra["llama14b_prefill"] = llama14b_prefill_leg()

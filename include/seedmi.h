@@ -62,7 +62,10 @@ int seedmi_check_device(void);
  * seedmi_layernorm_stats_finalize launches; large batches only),
  * "skinny_waves" / "skinny_rows"
  * (decode GEMM; "skinny_nt" = 0, temporal weight loads, exists in the devtools build only), "skinny_splitk" (which kernel seedmi_gemm_skinny_norm_ws_bf16 runs: 0 = the one-tile-per-workgroup kernel | 1 = the split-K kernel, uncut where the shape divides into whole tiles per workgroup: the default | 2 = the split-K kernel, always cut | 3 = the split-K kernel only where the one-tile form would leave its last round of workgroups under 95 % full), "decode_fused" (0|1 RoPE + append inside decode attention), "decode_attn_early" (fused decode attention: 0 = cached rows requested after the rotation | 1 = first batch of key rows requested ahead of it: the default | 2 = key and value rows; same bits), "prefill_tiled" (0|1), "attn_trv" / "attn_vit"
- * (attention kernel selection; attn_vit: 0 off | 1 twelve-wave ViT kernel | 2 sixteen-wave ViT kernel for 257 tokens).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
+ * (attention kernel selection; attn_vit, for the ViT's 257-token / head-dim-88 shape: 0 = generic full-row kernel | 1 = twelve-wave ViT kernel |
+ * 2 = sixteen-wave ViT kernel | 3 = sixteen-wave kernel with 16-byte output stores: the DEFAULT, same bits as 1 and 2 |
+ * 4 = sixteen-wave kernel with "flash" normalisation (P rounded to half BEFORE the division by the row sum): faster, but NOT
+ * bit-compatible with 0-3 - it moves a rounding point of eva_vit.py:139-156 by about 0.8 bf16 ulp rms, token ids form their own equality group).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
 int seedmi_set_option(const char* key, int value);
 
@@ -218,6 +221,9 @@ int seedmi_gemm_skinny_norm_bf16(int M, int N, int K, const void* A, int a_packe
  * workspace == NULL, M > 32, a_packed == 0 or seedmi_set_option("skinny_splitk", 0) select the kernel of seedmi_gemm_skinny_norm_bf16;
  * all forms give the same values up to the order of the fp32 K summation. */
 size_t seedmi_gemm_skinny_workspace_bytes(void);
+/* Reads (and, once reported, clears) the sticky error word of such a workspace: SEEDMI_OK, or SEEDMI_E_HIP with the workgroup that gave up
+ * in seedmi_last_error().  SYNCHRONISES `stream` (one 4-byte copy to the host): call it after a decode loop, not inside one. */
+int seedmi_gemm_skinny_ws_status(void* workspace, size_t workspace_bytes, void* stream);
 int seedmi_gemm_skinny_norm_ws_bf16(int M, int N, int K, const void* A, int a_packed, const void* W_packed, float rms_eps,
                                     const void* residual, int ldr, int epilogue, void* C, int ldc, int c_packed, void* x_packed_out,
                                     void* workspace, size_t workspace_bytes, void* stream);
@@ -279,11 +285,30 @@ typedef struct {                     /* optional device outputs for parity check
     void* z;                         /* [B*n_query, code_dim] bf16                        */
 } seedmi_tokenizer_taps_t;
 
+/* Sized for any number of sub-batches (see below), so one allocation serves every setting. */
 size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights_t* w, int batch);
 /* Blip2QformerQuantizer.get_codebook_indices + ImageTokenizer.encode (qformer_quantizer.py:288-307,
  * seed_llama_tokenizer.py:75-90): images [B,3,S,S] (fp32 or bf16) -> ids int64 [B, n_query] in [0, n_embed). */
 int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch, void* ids_i64,
                     const seedmi_tokenizer_taps_t* taps, void* workspace, size_t workspace_bytes, void* stream);
+/* Sub-batch overlap and the ONE piece of state this library owns.  A batch >= 32 is split into seedmi_set_option("tokenize_streams")
+ * sub-batches (default 2) that run on side streams forked from / joined into `stream` by events, so that one sub-batch's kernels fill the
+ * partial last round of the other's GEMMs (+5 %); to the caller the call is still ordered on `stream` alone.  seedmi_tokenize creates those
+ * objects itself at first use - per calling thread and device up to 3 non-blocking streams and 4 events, kept until the thread exits -
+ * which is the exception to "nothing is created inside the library".  A caller that wants none of it either sets "tokenize_streams" to 1
+ * (everything on `stream`) or passes its OWN objects through seedmi_tokenize_fj: hipStream_t side_stream[n_side] (any streams of the
+ * device other than `stream`), hipEvent_t fork_event and join_event[n_side] (hipEventDisableTiming is enough), n_side = 0..3 (the
+ * number of sub-batches is n_side + 1 whatever the option says; a batch below 32 is never split).  The objects must not be in use by a
+ * concurrent call.  fj == NULL is seedmi_tokenize. */
+typedef struct {
+    void* side_stream[3];
+    void* fork_event;
+    void* join_event[3];
+    int n_side;
+} seedmi_fork_join_t;
+int seedmi_tokenize_fj(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch, void* ids_i64,
+                       const seedmi_tokenizer_taps_t* taps, void* workspace, size_t workspace_bytes, const seedmi_fork_join_t* fj,
+                       void* stream);
 
 /* ---- the step after the path: next-token selection ------------------------------------------------------------------- */
 /* Greedy argmax (uniforms_f32 == NULL or top_p == 0; first index on ties) or temperature + top-p sampling of one token per row
@@ -297,15 +322,6 @@ int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int
 int seedmi_sample_token_bf16(const void* logits, int ldl, int batch, int vocab, float temperature, float top_p,
                              const void* uniforms_f32, const void* step_dev, int step_offset, void* tok_out_i64,
                              void* history_i64, int history_ld, int n_steps, void* stream);
-
-/* ---- calibration (not on the product path) ---------------------------------------------------------------------------- */
-/* Streams `bytes` of device memory with 16-byte non-temporal loads from 256*blocks_per_cu workgroups (the decode GEMMs' access
- * pattern) and discards them: the HBM read rate this box actually delivers, for the "vs measured" roofline. */
-int seedmi_bench_stream_read(const void* p, size_t bytes, int blocks_per_cu, void* scratch4, void* stream);
-/* MFMA-only loop from registers (shape 0: v_mfma_f32_16x16x32_bf16, 1: v_mfma_f32_32x32x16_bf16; 8 waves per workgroup, four
- * accumulator chains each, varied non-zero operands): the matrix-pipe rate this box sustains at the clock its power budget allows.
- * *flops_out = floating-point operations of the launch. */
-int seedmi_bench_mfma_bf16(int shape, int iters, int workgroups, void* scratch4, double* flops_out, void* stream);
 
 /* ---- the step before the path: image pre-processing -------------------------------------------------------------- */
 #define SEEDMI_RESIZE_BILINEAR 2   /* PIL.Image.BILINEAR: transforms.Resize default, models/transforms.py:13,16      */
@@ -396,6 +412,10 @@ int seedmi_llama_forward_io(const seedmi_llama_weights_t* w, const void* ids_i64
  * position of every slot).  Rows are independent: an idle slot (length 0, any token) costs its share of the weight stream only. */
 int seedmi_llama_decode_slots(const seedmi_llama_weights_t* w, const void* tok_i64, const void* lens_i32, int batch, void* logits,
                               int ldl, void* workspace, size_t workspace_bytes, void* stream);
+/* seedmi_gemm_skinny_ws_status for the split-K area inside a decode workspace (the one passed to the T = 1 forward / decode_slots calls
+ * of this batch): SEEDMI_OK when every decode step since the last check completed its cut tiles, SEEDMI_E_HIP otherwise (the logits of
+ * those steps are then invalid).  SYNCHRONISES `stream`; a decode loop calls it once at its end (seed_amd/llama_engine.py does). */
+int seedmi_llama_decode_status(const seedmi_llama_weights_t* w, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,8 @@ prepare_inputs_for_generation 745-776, _reorder_cache 778-783, _init_weights 363
 """
 from typing import List, Optional, Tuple, Union
 
+import warnings
+
 import torch
 import torch.nn as nn
 from torch.nn import CrossEntropyLoss
@@ -206,6 +208,14 @@ class LlamaForCausalLM(PreTrainedModel, GenerationMixin):
                 for l, (k, v) in enumerate(past_key_values):
                     eng.k_cache[l][:B, :, :past_len].copy_(k)
                     eng.v_cache[l][:B, :, :past_len].copy_(v)
+        if attention_mask is not None and past_len == 0 and attention_mask.numel() > 0 and bool((attention_mask == 0).any()):
+            # the reference's eval path ignores padding masks too (xformers gets a LowerTriangularMask or nothing,
+            # llama_xformer.py:244-256), so a padded batch is computed as if every position were a token - in both.  Parity is
+            # defined for unpadded, equal-length batches; say so instead of silently returning answers for padding.  Checked on
+            # prefill calls only (one host sync), not on every cached decode step.
+            warnings.warn("LlamaForCausalLM.forward: attention_mask contains zeros (a padded batch); padding masks are not applied - "
+                          "like the reference's xformers path - so padded rows attend to their padding.  Use unpadded, equal-length "
+                          "batches (or one sequence per call).", RuntimeWarning, stacklevel=2)
         if position_ids is not None:
             position_ids = position_ids.view(-1, T).long()                      # :541
             if position_ids.shape[0] == 1 and B > 1:

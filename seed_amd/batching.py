@@ -71,6 +71,15 @@ class ContinuousBatcher:
         for req in self.active.values():
             if req["prompt"].numel() + req["max_new"] - 1 > eng.tmax:
                 raise L.SeedmiError("the KV cache was shrunk below the context of a request in flight")
+        # requests still waiting were clamped in submit() against the OLD context: clamp again (generate() stops at the context
+        # limit); one whose prompt no longer fits finishes empty instead of failing a prefill with a slot in hand
+        for req in list(self.waiting):
+            room = eng.tmax - req["prompt"].numel() + 1
+            if room < 1:
+                self.waiting.remove(req)
+                self.done[req["id"]] = []
+            else:
+                req["max_new"] = min(req["max_new"], room)
         self._graph, self._slot_w = None, {}
         self._ws = torch.empty(self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), self.B, 1), dtype=torch.uint8, device=eng.device)
         self._ws_prefill = None
@@ -141,32 +150,43 @@ class ContinuousBatcher:
         return not self.waiting and not self.active
 
     def _admit(self):
-        eng = self.eng
+        self._sync_generation()                                                  # re-clamp waiting requests before any slot is taken
         while self.waiting and self.free:
             req = self.waiting.popleft()
             s = self.free.popleft()
-            ids = req["prompt"].to(eng.device).view(1, -1)
-            T0 = ids.shape[1]
-            pos = torch.arange(T0, dtype=torch.int64, device=eng.device).view(1, T0)
-            lg = torch.empty(1, eng.vocab_pad, dtype=torch.bfloat16, device=eng.device)
-            need = self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), 1, T0)
-            if self._ws_prefill is None or self._ws_prefill.numel() < need:
-                self._ws_prefill = torch.empty(need, dtype=torch.uint8, device=eng.device)
-            ws = self._ws_prefill
-            with torch.cuda.device(eng.device):
-                L.check(self.lib.seedmi_llama_forward_io(C.byref(self._slot_weights(s)), L.ptr(ids), None, L.ptr(pos), 1, T0, 0, None, 1,
-                                                         L.ptr(lg), eng.vocab_pad, None, L.ptr(ws), ws.numel(), L.stream_ptr()),
-                        "prefill into a slot")
-            first = torch.empty(1, dtype=torch.int64, device=eng.device)
-            u = None
-            if self.top_p > 0.0:
-                u = torch.rand(1, 1, dtype=torch.float32, device=eng.device, generator=self.gen)
-            eng.select_token(lg, first, self.top_p, self.temperature, u, None, 0, None)
-            self.tok[s:s + 1].copy_(first)
-            self.lens[s:s + 1].fill_(T0)
-            self.inc[s:s + 1].fill_(1)
-            req.update(slot=s, tokens=[], first=first, emitted=0)
-            self.active[s] = req
+            try:
+                self._prefill_into(req, s)
+            except Exception:
+                # the slot goes back and the request is dropped with an empty result: a failed prefill must not leak the KV row (after
+                # batch_cap leaks run() would spin with waiting requests and no free slot) nor poison the requests behind it
+                self.free.appendleft(s)
+                self.done[req["id"]] = []
+                raise
+
+    def _prefill_into(self, req, s: int):
+        eng = self.eng
+        ids = req["prompt"].to(eng.device).view(1, -1)
+        T0 = ids.shape[1]
+        pos = torch.arange(T0, dtype=torch.int64, device=eng.device).view(1, T0)
+        lg = torch.empty(1, eng.vocab_pad, dtype=torch.bfloat16, device=eng.device)
+        need = self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), 1, T0)
+        if self._ws_prefill is None or self._ws_prefill.numel() < need:
+            self._ws_prefill = torch.empty(need, dtype=torch.uint8, device=eng.device)
+        ws = self._ws_prefill
+        with torch.cuda.device(eng.device):
+            L.check(self.lib.seedmi_llama_forward_io(C.byref(self._slot_weights(s)), L.ptr(ids), None, L.ptr(pos), 1, T0, 0, None, 1,
+                                                     L.ptr(lg), eng.vocab_pad, None, L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "prefill into a slot")
+        first = torch.empty(1, dtype=torch.int64, device=eng.device)
+        u = None
+        if self.top_p > 0.0:
+            u = torch.rand(1, 1, dtype=torch.float32, device=eng.device, generator=self.gen)
+        eng.select_token(lg, first, self.top_p, self.temperature, u, None, 0, None)
+        self.tok[s:s + 1].copy_(first)
+        self.lens[s:s + 1].fill_(T0)
+        self.inc[s:s + 1].fill_(1)
+        req.update(slot=s, tokens=[], first=first, emitted=0)
+        self.active[s] = req
 
     def _retire(self, s: int):
         req = self.active.pop(s)
@@ -208,5 +228,6 @@ class ContinuousBatcher:
             for s, req in list(self.active.items()):
                 if self._take(req, hist[s].tolist()):
                     self._retire(s)
+        eng.decode_status(self.B, self._ws)                                       # a cut split-K tile that lost its partner is an error, not a token
         out, self.done = self.done, {}
         return out

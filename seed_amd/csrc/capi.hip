@@ -55,87 +55,3 @@ extern "C" int seedmi_check_device(void) {
     }
     return SEEDMI_OK;
 }
-
-// ---- calibration microbenchmarks ("re-measure ... with a streaming-copy microbench"): what this box's
-// HBM delivers to the access pattern the decode GEMMs use (16-byte non-temporal loads, every CU streaming a contiguous slice)
-namespace {
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <int U>
-__global__ __launch_bounds__(512) void stream_read_kernel(const u32x4_t* __restrict__ p, size_t n16, unsigned* __restrict__ out) {
-    const size_t per_block = (n16 + gridDim.x - 1) / gridDim.x;
-    const size_t b0 = (size_t)blockIdx.x * per_block;
-    const size_t b1 = b0 + per_block < n16 ? b0 + per_block : n16;
-    unsigned acc = 0;
-    size_t i = b0 + threadIdx.x;
-    for (; i + (size_t)(U - 1) * 512 < b1; i += (size_t)U * 512) {
-        u32x4_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + (size_t)u * 512);
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
-    }
-    for (; i < b1; i += 512) {
-        const u32x4_t v = __builtin_nontemporal_load(p + i);
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
-    }
-    if (acc == 0x9e3779b9u) out[0] = acc;          // practically never: keeps the loads alive without a store per thread
-}
-
-// MFMA-only loop: what the matrix pipes of this box sustain at the clock its power budget allows when nothing else runs (operands
-// from registers, four independent accumulator chains per wave, two waves per SIMD, varied non-zero operand bits - zero-filled
-// operands clock ~20 % higher and would flatter the ceiling).  SHAPE 0: v_mfma_f32_16x16x32_bf16, 1: v_mfma_f32_32x32x16_bf16.
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-template <int SHAPE>
-__global__ __launch_bounds__(512) void mfma_peak_kernel(float* __restrict__ out, int iters) {
-    const unsigned t = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
-    bf16x8 a, b;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        a[i] = (short)(0x3c00 + ((t >> i) & 0x3ff) - ((i & 1) << 15));      // bf16 values of magnitude ~0.01..0.03, mixed signs
-        b[i] = (short)(0x3c80 + ((t >> (i + 7)) & 0x3ff) - (((i >> 1) & 1) << 15));
-    }
-    float keep = 0.f;
-    if (SHAPE == 0) {
-        f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
-        for (int i = 0; i < iters; ++i) {
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, b, c3, 0, 0, 0);
-        }
-        keep = c0[0] + c1[1] + c2[2] + c3[3];
-    } else {
-        f32x16_t c0 = {}, c1 = {}, c2 = {}, c3 = {};
-        for (int i = 0; i < iters; ++i) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
-        }
-        keep = c0[0] + c1[5] + c2[10] + c3[15];
-    }
-    if (keep == 123.456f) out[0] = keep;
-}
-}  // namespace
-
-extern "C" int seedmi_bench_mfma_bf16(int shape, int iters, int workgroups, void* scratch4, double* flops_out, void* stream) {
-    if (!scratch4 || iters < 1 || workgroups < 1 || (shape != 0 && shape != 1)) {
-        seedmi_set_error("seedmi_bench_mfma_bf16: bad arguments");
-        return SEEDMI_E_SHAPE;
-    }
-    if (shape == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, (float*)scratch4, iters);
-    else hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, (float*)scratch4, iters);
-    // one MFMA of either shape is 2 * 16*16*32 = 2 * 32*32*16 = 16384 * 2 / ... flops per wave
-    if (flops_out) *flops_out = (double)workgroups * 8.0 * (double)iters * 4.0 * (shape == 0 ? 2.0 * 16 * 16 * 32 : 2.0 * 32 * 32 * 16);
-    return seedmi_check_launch("mfma_peak");
-}
-
-extern "C" int seedmi_bench_stream_read(const void* p, size_t bytes, int blocks_per_cu, void* scratch4, void* stream) {
-    if (!p || !scratch4 || bytes < 16 || ((uintptr_t)p & 15) || blocks_per_cu < 1 || blocks_per_cu > 8) {
-        seedmi_set_error("seedmi_bench_stream_read: bad arguments");
-        return SEEDMI_E_SHAPE;
-    }
-    hipLaunchKernelGGL(stream_read_kernel<8>, dim3(256 * blocks_per_cu), dim3(512), 0, (hipStream_t)stream, (const u32x4_t*)p,
-                       bytes / 16, (unsigned*)scratch4);
-    return seedmi_check_launch("stream_read");
-}

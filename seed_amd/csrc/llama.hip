@@ -338,8 +338,10 @@ int launch_skinny(const SkinnyParams& p, hipStream_t s) {
 // A tile cut by a range boundary is finished by the workgroup that holds its HEAD (k-step 0; always that workgroup's last segment): the
 // others publish their fp32 image (+ their part of the RMSNorm row sums) write-through and raise a flag, the owner adds them in
 // workgroup order - a fixed summation order, so results are reproducible run to run.  Flags are consumed and cleared by the owner
-// (the flag area is all-zero between launches: graph replays need no epoch).  All workgroups must be resident (grid <= CUs x
-// occupancy, checked by the launcher); waits are bounded and a lost partner is recorded in the sticky error word, like gemm256's stream-K.
+// (the flag area is all-zero between launches: graph replays need no epoch).  All workgroups must be resident: the launcher sizes the
+// grid as CUs x WGS and verifies once per kernel and device, with the occupancy query, that WGS workgroups fit a CU; residency can still
+// be lost to a concurrent kernel of another stream, so waits are bounded and a lost partner is recorded in the STICKY error word (the
+// last word of the flag area: the per-step clear leaves it alone, seedmi_gemm_skinny_ws_status / seedmi_llama_decode_status report it).
 // Logical workgroup order runs XCD by XCD (q = (id % 8) * (G / 8) + id / 8), so an image is produced and consumed on one L2.
 #ifndef SEEDMI_SK_NT
 // weight loads of the split-K kernel: 1 = non-temporal (`nt`), 0 = plain (A/B builds: python -m seed_amd.build --variant sknt0 -DSEEDMI_SK_NT=0).
@@ -631,6 +633,24 @@ int launch_skinny_sk_r(const SkinnyParams& p, void* ws, int grid, hipStream_t s)
     x.rem = (int)(total % grid);
     x.cut = (x.rem != 0 || (x.per % x.ks) != 0) ? 1 : 0;
     x.ks_inv = 1.0f / (float)x.ks;
+    if (x.cut) {
+        // a cut tile's owner waits for its partners: every workgroup of the grid must be resident.  Checked once per device for this
+        // instantiation (the answer depends on the kernel's registers / LDS only)
+        static std::atomic<int> fits[SEEDMI_MAX_DEVICES] = {};
+        const int dev = seedmi_current_device();
+        int ok = fits[dev].load(std::memory_order_relaxed);
+        if (!ok) {
+            int n1 = 0, n2 = 0;
+            const hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, gemm_skinny_sk_kernel<1, EPI, R, WGS>, 512, 0);
+            const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, gemm_skinny_sk_kernel<2, EPI, R, WGS>, 512, 0);
+            ok = (e1 == hipSuccess && e2 == hipSuccess && n1 >= WGS && n2 >= WGS) ? 1 : -1;
+            fits[dev].store(ok, std::memory_order_relaxed);
+        }
+        if (ok < 0 || grid > WGS * seedmi_device_cus(dev)) {
+            seedmi_set_error("seedmi_gemm_skinny: the split-K kernel's grid of %d workgroups is not resident on this device", grid);
+            return SEEDMI_E_HIP;
+        }
+    }
     if (p.M <= 16) hipLaunchKernelGGL((gemm_skinny_sk_kernel<1, EPI, R, WGS>), dim3(grid), dim3(512), 0, s, p, x);
     else hipLaunchKernelGGL((gemm_skinny_sk_kernel<2, EPI, R, WGS>), dim3(grid), dim3(512), 0, s, p, x);
     return seedmi_check_launch("gemm_skinny_sk");
@@ -1695,6 +1715,41 @@ extern "C" int seedmi_llama_attention_bf16(const void* q, int ldq, const void* k
     return seedmi_check_launch("attn_prefill");
 }
 
+// The sticky error word of a split-K workspace: 0, or 1 + the id of a workgroup whose bounded wait for a partner's image ran out (its
+// tile of C is then wrong).  Synchronises `stream`, reads the word and clears it once reported.
+extern "C" int seedmi_gemm_skinny_ws_status(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < SK2_WS_BYTES) {
+        seedmi_set_error("seedmi_gemm_skinny_ws_status: not a split-K workspace (seedmi_gemm_skinny_workspace_bytes())");
+        return SEEDMI_E_SHAPE;
+    }
+    unsigned word = 0;
+    unsigned* dev = (unsigned*)workspace + (SK2_FLAG_WORDS - 1);
+    if (hipMemcpyAsync(&word, dev, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        seedmi_set_error("seedmi_gemm_skinny_ws_status: reading the error word failed");
+        return SEEDMI_E_HIP;
+    }
+    if (word == 0) return SEEDMI_OK;
+    (void)hipMemsetAsync(dev, 0, 4, (hipStream_t)stream);
+    seedmi_set_error("split-K decode GEMM: workgroup %u gave up waiting for a partner's partial tile (the grid was not fully resident, "
+                     "e.g. another stream's kernel held CUs): results computed through this workspace since the last check are invalid", word - 1);
+    return SEEDMI_E_HIP;
+}
+
+extern "C" int seedmi_llama_decode_status(const seedmi_llama_weights_t* w, int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!w || batch <= 0 || !workspace) {
+        seedmi_set_error("seedmi_llama_decode_status: bad arguments");
+        return SEEDMI_E_SHAPE;
+    }
+    const LlamaWs t = carve(w, batch, 1, workspace);
+    if (workspace_bytes < t.bytes) {
+        seedmi_set_error("seedmi_llama_decode_status: workspace smaller than seedmi_llama_workspace_bytes(w, batch, 1)");
+        return SEEDMI_E_SHAPE;
+    }
+    if (!t.sk) return SEEDMI_OK;                       // this batch does not take the split-K kernels
+    return seedmi_gemm_skinny_ws_status(t.sk, SK2_WS_BYTES, stream);
+}
+
 extern "C" size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, int batch, int T) {
     if (!w || batch <= 0 || T <= 0) return 0;
     return carve(w, batch, T, nullptr).bytes;
@@ -1784,7 +1839,7 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
             return SEEDMI_E_HIP;
         }
     } else if (fused_first) {
-        CK(seedmi_embed_rows_decode(ids_i64, w->embed, h, t.x, h, t.xn, M, h, w->vocab, sk, sk ? SK2_FLAG_WORDS : 0, stream));
+        CK(seedmi_embed_rows_decode(ids_i64, w->embed, h, t.x, h, t.xn, M, h, w->vocab, sk, sk ? SK2_FLAG_WORDS - 1 : 0, stream));   // (not the sticky error word)
     } else {
         CK(seedmi_embed_rows(ids_i64, w->embed, h, t.x, h, M, h, w->vocab, stream));
     }
@@ -1798,7 +1853,7 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
         }
         return SEEDMI_OK;
     };
-    if (sk && !fused_first && hipMemsetAsync(sk, 0, SK2_FLAG_WORDS * 4, (hipStream_t)stream) != hipSuccess) {     // (the kernels leave the
+    if (sk && !fused_first && hipMemsetAsync(sk, 0, (SK2_FLAG_WORDS - 1) * 4, (hipStream_t)stream) != hipSuccess) {     // (the kernels leave the
         seedmi_set_error("seedmi_llama_forward: clearing the split-K flag words failed");                       //  words zero: safety net)
         return SEEDMI_E_HIP;
     }

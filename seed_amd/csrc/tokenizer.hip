@@ -361,6 +361,12 @@ extern "C" size_t seedmi_tokenize_workspace_bytes(const seedmi_tokenizer_weights
 extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch,
                                void* ids_i64, const seedmi_tokenizer_taps_t* taps, void* workspace,
                                size_t workspace_bytes, void* stream) {
+    return seedmi_tokenize_fj(w, images, images_fp32, batch, ids_i64, taps, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int seedmi_tokenize_fj(const seedmi_tokenizer_weights_t* w, const void* images, int images_fp32, int batch,
+                                  void* ids_i64, const seedmi_tokenizer_taps_t* taps, void* workspace,
+                                  size_t workspace_bytes, const seedmi_fork_join_t* caller_fj, void* stream) {
     if (!w || !images || !ids_i64 || batch <= 0) {
         seedmi_set_error("seedmi_tokenize: null argument or batch=%d", batch);
         return SEEDMI_E_SHAPE;
@@ -370,7 +376,7 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
                          w->img_size, w->patch, w->vit_dim, w->vit_heads, w->qf_dim, w->qf_heads);
         return SEEDMI_E_SHAPE;
     }
-    const size_t need = total_ws(w, batch);
+    const size_t need = caller_fj ? ws_for(w, batch, batch >= SPLIT_MIN_BATCH ? caller_fj->n_side + 1 : 1) : total_ws(w, batch);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) {
         seedmi_set_error("seedmi_tokenize: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
         return SEEDMI_E_ALIGN;
@@ -378,7 +384,24 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
     const int grid = w->img_size / w->patch;
     const size_t NT = (size_t)grid * grid + 1;
     const size_t img_bytes = (size_t)3 * w->img_size * w->img_size * (images_fp32 ? 4 : 2);
-    const int nparts = n_parts(batch);
+    // caller-owned fork/join objects decide the number of sub-batches themselves (n_side + 1); the library's own set follows the option
+    int nparts = n_parts(batch);
+    if (caller_fj) {
+        if (caller_fj->n_side < 0 || caller_fj->n_side > MAX_PARTS - 1) {
+            seedmi_set_error("seedmi_tokenize_fj: n_side=%d (0..%d)", caller_fj->n_side, MAX_PARTS - 1);
+            return SEEDMI_E_SHAPE;
+        }
+        nparts = (batch >= SPLIT_MIN_BATCH) ? caller_fj->n_side + 1 : 1;
+        if (nparts > 1 && !caller_fj->fork_event) {
+            seedmi_set_error("seedmi_tokenize_fj: fork_event is NULL");
+            return SEEDMI_E_SHAPE;
+        }
+        for (int i = 0; i + 1 < nparts; ++i)
+            if (!caller_fj->side_stream[i] || !caller_fj->join_event[i]) {
+                seedmi_set_error("seedmi_tokenize_fj: side_stream[%d] / join_event[%d] is NULL", i, i);
+                return SEEDMI_E_SHAPE;
+            }
+    }
     const bool split = nparts > 1;
     Part parts[MAX_PARTS];
     int b_begin = 0;
@@ -399,8 +422,18 @@ extern "C" int seedmi_tokenize(const seedmi_tokenizer_weights_t* w, const void* 
         b_begin += p.B;
     }
     ForkJoin* fj = nullptr;
+    ForkJoin given;
     if (split) {
-        CK(ensure_forkjoin(&fj));
+        if (caller_fj) {
+            given.fork = (hipEvent_t)caller_fj->fork_event;
+            for (int i = 0; i + 1 < nparts; ++i) {
+                given.side[i] = (hipStream_t)caller_fj->side_stream[i];
+                given.join[i] = (hipEvent_t)caller_fj->join_event[i];
+            }
+            fj = &given;
+        } else {
+            CK(ensure_forkjoin(&fj));
+        }
         HIPCK(hipEventRecord(fj->fork, (hipStream_t)stream));
         for (int i = 1; i < nparts; ++i) {
             parts[i].s = fj->side[i - 1];

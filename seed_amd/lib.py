@@ -56,6 +56,10 @@ class TokenizerTaps(C.Structure):
     _fields_ = [("image_embeds", _vp), ("qformer_out", _vp), ("z", _vp)]
 
 
+class ForkJoin(C.Structure):
+    _fields_ = [("side_stream", _vp * 3), ("fork_event", _vp), ("join_event", _vp * 3), ("n_side", _i)]
+
+
 class LlamaLayer(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_w", "qkv_w", "o_w", "ln2_w", "gate_up_w", "down_w", "k_cache", "v_cache",
                                     "qkv_wp", "o_wp", "gate_up_wp", "down_wp")]
@@ -103,6 +107,8 @@ SIGNATURES = {
     "seedmi_pack_skinny_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "seedmi_gemm_skinny_norm_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "seedmi_gemm_skinny_workspace_bytes": (C.c_size_t, []),
+    "seedmi_gemm_skinny_ws_status": (_i, [_vp, C.c_size_t, _vp]),
+    "seedmi_llama_decode_status": (_i, [C.POINTER(LlamaWeights), _i, _vp, C.c_size_t, _vp]),
     "seedmi_gemm_skinny_norm_ws_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _i, _i, _vp, _i, _i, _vp, _vp, C.c_size_t, _vp]),
     "seedmi_pack_activations_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "seedmi_gemm_skinny_packed_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
@@ -110,9 +116,9 @@ SIGNATURES = {
     "seedmi_tokenize_workspace_bytes": (C.c_size_t, [C.POINTER(TokenizerWeights), _i]),
     "seedmi_tokenize": (_i, [C.POINTER(TokenizerWeights), _vp, _i, _i, _vp, C.POINTER(TokenizerTaps), _vp,
                              C.c_size_t, _vp]),
+    "seedmi_tokenize_fj": (_i, [C.POINTER(TokenizerWeights), _vp, _i, _i, _vp, C.POINTER(TokenizerTaps), _vp,
+                                C.c_size_t, C.POINTER(ForkJoin), _vp]),
     "seedmi_sample_token_bf16": (_i, [_vp, _i, _i, _i, C.c_float, C.c_float, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
-    "seedmi_bench_stream_read": (_i, [_vp, C.c_size_t, _i, _vp, _vp]),
-    "seedmi_bench_mfma_bf16": (_i, [_i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
     "seedmi_preprocess_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "seedmi_preprocess_image_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         _vp, _i, _vp, _vp, C.c_size_t, _vp]),

@@ -132,6 +132,17 @@ class LlamaEngine:
     def reset(self):
         self.past_len = 0
 
+    def decode_status(self, B: int, ws: Optional[torch.Tensor] = None):
+        """Raise if a split-K decode GEMM of this batch gave up waiting for a partner workgroup since the last check (its tile of the
+        logits is then wrong): seedmi_llama_decode_status reads the sticky error word of the decode workspace.  Synchronises the
+        stream - called once at the END of a decode loop, never inside one."""
+        ws = self._ws if ws is None else ws
+        if ws is None:
+            return
+        with torch.cuda.device(self.device):
+            L.check(self.lib.seedmi_llama_decode_status(C.byref(self.w), B, L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "seedmi_llama_decode_status")
+
     def forward(self, input_ids: Optional[torch.Tensor], position_ids: Optional[torch.Tensor] = None,
                 past_len: Optional[int] = None, last_only: bool = False, inputs_embeds: Optional[torch.Tensor] = None,
                 hidden_states_out: Optional[list] = None) -> torch.Tensor:
@@ -309,6 +320,7 @@ class LlamaEngine:
             return tok
         replay, out = self.capture_decode_graph(tok, n_new, top_p, temperature, uniforms)
         replay(n_new - 1)
+        self.decode_status(B)
         return out
 
     def greedy_decode(self, prompt_ids: torch.Tensor, n_new: int):
@@ -323,4 +335,5 @@ class LlamaEngine:
             steps.append(logits[:, 0])
             tok = logits[:, 0].float().argmax(-1, keepdim=True)
             out.append(tok)
+        self.decode_status(prompt_ids.shape[0])
         return torch.cat(out, dim=1), torch.stack(steps, dim=1)

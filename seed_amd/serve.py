@@ -69,11 +69,16 @@ class GenerateService:
     def _batcher(self, top_p: float, temperature: float):
         if self._batcher_factory is None:
             from .batching import ContinuousBatcher
-        if temperature is None or temperature <= 0.0 or top_p is None or top_p <= 0.0:
-            top_p, temperature = 0.0, 1.0             # degenerate sampling requests are greedy (temperature -> 0 limit)
         # client-supplied floats key device-side state: quantise them (1e-3 is far below any audible difference in sampling) and keep
-        # at most ``max_batchers`` configurations alive, evicting the least recently used IDLE one (its graph and buffers are freed)
-        key = (round(float(top_p), 3), round(float(temperature), 3))
+        # at most ``max_batchers`` configurations alive, evicting the least recently used IDLE one (its graph and buffers are freed).
+        # The degenerate check comes AFTER the quantisation (a temperature in (0, 0.0005) used to round to a key of 0.0,
+        # which seedmi_sample_token_bf16 rejects only once a KV slot had been taken): degenerate requests are greedy
+        # (temperature -> 0 limit; top_p -> 0 keeps the single most likely token)
+        top_p = 0.0 if top_p is None else round(float(top_p), 3)
+        temperature = 0.0 if temperature is None else round(float(temperature), 3)
+        if not (temperature > 0.0) or not (top_p > 0.0):
+            top_p, temperature = 0.0, 1.0
+        key = (top_p, temperature)
         if key in self._batchers:
             self._batchers.move_to_end(key)
             return self._batchers[key]
@@ -158,7 +163,7 @@ class GenerateService:
                     raise ValueError(f"prompt of {len(q['input_ids'])} tokens exceeds the context of {tmax}")
                 if int(q['max_new_tokens']) < 1:
                     raise ValueError("max_new_tokens must be at least 1")
-            except (AssertionError, ValueError, KeyError, TypeError) as e:
+            except Exception as e:        # incl. OSError / PIL.UnidentifiedImageError of a bad image payload, RuntimeError of the encoder
                 if raise_asserts and isinstance(e, AssertionError):
                     raise
                 q = None
@@ -176,8 +181,17 @@ class GenerateService:
                     cb.cancel(rid)
             raise
         results = {}
-        for cb in {id(cb): cb for cb, _ in tickets.values()}.values():
-            results[id(cb)] = cb.run()
+        batchers = {id(cb): cb for cb, _ in tickets.values()}
+        try:
+            for cb in batchers.values():
+                results[id(cb)] = cb.run()
+        except Exception:
+            # a decode loop failed midway: nothing of this call may stay queued in the batchers that have not run yet (or in the
+            # failed one), or the next call would decode and discard it
+            for i, (cb, rid) in tickets.items():
+                if id(cb) not in results and hasattr(cb, "cancel"):
+                    cb.cancel(rid)
+            raise
         out = []
         for i, q in enumerate(parsed):
             if q is None:

@@ -91,7 +91,7 @@ def run(encode_fn: Callable[[torch.Tensor], torch.Tensor], items: List, load_fn:
     return writer.total
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", required=True, help="image directory or synthetic:N")
     ap.add_argument("--save_dir", required=True)
@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpu-preprocess", action="store_true",
                     help="resize/normalise on the device (seedmi_preprocess_image_u8, bit-exact with the PIL path); "
                          "only the JPEG decode stays on the host")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)

@@ -204,3 +204,24 @@ def make_llama_state_dict(cfg: LlamaConfig, seed: int = 0, device="cpu", dtype=t
     nw("model.norm.weight")
     w("lm_head.weight", (cfg.vocab, h))
     return sd
+
+
+def make_llama_successor_state_dict(cfg: LlamaConfig, seed: int = 0, device="cpu", dtype=torch.float32, norm_jitter: float = 0.0,
+                                    embed_std: float = 1.2, perm_seed: int = 5) -> Dict[str, torch.Tensor]:
+    """A second synthetic LLaMA whose logits are PEAKED.  With every weight ~ N(0, 0.02) the final hidden state is a
+    random feature of the context and the top-2 logit gap (~0.1) sits inside the bf16 noise of a 32-layer stack (~0.3): greedy-token
+    parity can then only be asserted on ~1 % of positions.  Here the body is the same N(0, 0.02) stack (llama_xformer.py:363-372) but
+    ``embed_tokens ~ N(0, embed_std)`` is large enough to survive the residual stream next to the layers' O(1)-per-layer contributions,
+    and ``lm_head.weight[j] = embed_tokens[perm[j]] * 0.02 / embed_std`` reads it back: the model computes next = perm^-1[last token], a
+    fixed-point-free "successor" walk through the vocabulary, with the fp32 top-2 gap several times the bf16 deviation on most
+    positions - while attention and the MLPs still contribute ~99 % of the stream's variance, so a kernel error large enough to matter
+    moves the argmax.  embed_std = 1.2 gives ~80 % confident positions at 8B dims, 32 layers (1.0: 47 %, 1.5: 100 %; measured with the
+    oracle in fp32 vs bf16).  Returns (state dict, successor) with successor[t] = the token the fp32 model should emit after t."""
+    sd = make_llama_state_dict(cfg, seed=seed, device=device, dtype=dtype, norm_jitter=norm_jitter)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1000003)
+    emb = _normal(gen, (cfg.vocab, cfg.hidden), embed_std, device)
+    perm = torch.randperm(cfg.vocab, generator=torch.Generator().manual_seed(perm_seed)).to(emb.device)
+    sd["model.embed_tokens.weight"] = emb.to(dtype)
+    sd["lm_head.weight"] = (emb.to(dtype).float()[perm] * (0.02 / embed_std)).to(dtype)
+    return sd, perm.argsort()

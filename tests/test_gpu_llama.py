@@ -191,12 +191,18 @@ def test_llama8b_width_parity_with_oracle(fold_norm):
     print(f"[8B-width greedy fold={fold_norm}] token agreement {same.float().mean().item():.3f}, confident {confident.float().mean().item():.3f}")
 
 
-def test_llama8b_full_depth_config3_parity():
-    """BASELINE.json config 3 as SURVEY 8d specifies it, at FULL depth: SEED-LLaMA-8B (32 layers, hidden 4096, FFN 11008, vocab 40194),
-    the config-3 prompt (BOS + 8 text + <img> + 32 image codes + </img> + 16 text = T0 59), B = 4 (oracle cost; the kernels' shapes do not
-    depend on B below 64), 128 greedy decode steps through the folded-norm hipGraph path that bench.py times.  Logits at the prefill's
-    last position and at decode steps {1, 2, 64, 128} against the oracle in fp32 and in the bf16 choreography, greedy ids against the fp32
-    oracle's argmax on confident rows at EVERY one of the 129 positions (llama_xformer.py:280-332, 496-627, 661-743).
+def _config3_prompt(B, T0=59):
+    g = torch.Generator().manual_seed(99)
+    prompt = torch.randint(3, 32000, (B, T0), generator=g)
+    prompt[:, 0] = 1
+    prompt[:, 9] = 32000 + 8192                                                             # <img>
+    prompt[:, 10:42] = 32000 + torch.randint(0, 8192, (B, 32), generator=g)
+    prompt[:, 42] = 32000 + 8193                                                            # </img>
+    return prompt
+
+
+def _full_depth_config3(sd, report_name, tag):
+    """BASELINE.json config 3 at FULL depth against the oracle; returns the report and the boolean maps the callers assert on.
 
     The engine decodes freely (graph replay); its own tokens are then teacher-forced through the eager path (logits kept at the probed
     steps) and through the oracle as ONE causal forward over prompt + tokens: position T0 - 1 + i of that forward is decode step i with
@@ -207,13 +213,7 @@ def test_llama8b_full_depth_config3_parity():
     cfg = C.LLAMA_8B
     B, T0, n_steps = 4, 59, 128
     probes = (0, 1, 2, 64, 128)
-    sd = make_llama_state_dict(cfg, seed=0, device="cuda", dtype=torch.bfloat16, norm_jitter=0.05)
-    g = torch.Generator().manual_seed(99)
-    prompt = torch.randint(3, 32000, (B, T0), generator=g)
-    prompt[:, 0] = 1
-    prompt[:, 9] = 32000 + 8192                                                             # <img>
-    prompt[:, 10:42] = 32000 + torch.randint(0, 8192, (B, 32), generator=g)
-    prompt[:, 42] = 32000 + 8193                                                            # </img>
+    prompt = _config3_prompt(B, T0)
     eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=T0 + n_steps + 5, fold_norm=True)
     graphed = eng.greedy_decode_graph(prompt.cuda(), n_steps + 1).clone()                   # tokens t_1 .. t_129 (128 decode steps)
     torch.cuda.synchronize()
@@ -231,7 +231,7 @@ def test_llama8b_full_depth_config3_parity():
     eager = torch.stack(eager, dim=1)
     assert torch.equal(eager, graphed), "teacher-forced eager path and hipGraph replay disagree"
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
-    del eng, sd
+    del eng
     gc.collect()
     torch.cuda.empty_cache()
     seq = torch.cat([prompt, graphed[:, :n_steps].cpu()], dim=1)                            # [B, T0 + 128]
@@ -239,19 +239,26 @@ def test_llama8b_full_depth_config3_parity():
     l32, _ = O.llama_forward(sd_cpu, cfg, seq, mode="fp32")
     l16, _ = O.llama_forward(sd_cpu, cfg, seq, mode="bf16")
     oracle_s = time.time() - t0
-    report = {"B": B, "T0": T0, "layers": cfg.layers, "oracle_seconds": round(oracle_s, 1), "steps": {}}
+    report = {"weights": tag, "B": B, "T0": T0, "layers": cfg.layers, "oracle_seconds": round(oracle_s, 1), "steps": {}}
     for i in probes:
         pos = T0 - 1 + i
         r32, r16 = l32[:, pos], l16[:, pos]
-        tag = "prefill-last" if i == 0 else f"decode step {i}"
-        _check_logits(kept[i], r32, r16, f"8B full depth {tag}")
-        # atol 2e-2 * max|logit| + rtol 2e-2 against the bf16 oracle (widened by the bf16 oracle's own distance from fp32:
-        # two bf16 pipelines that round in different places are each that far from the truth)
+        what = "prefill-last" if i == 0 else f"decode step {i}"
+        _check_logits(kept[i], r32, r16, f"8B full depth [{tag}] {what}")
+        # SURVEY 8d as written: atol 2e-2 * max|logit| + rtol 2e-2 against the bf16 oracle.  REPORTED un-widened (what fraction of the
+        # logits meets it and by how much the worst one misses), ASSERTED widened by the bf16 oracle's own distance from fp32: two bf16
+        # pipelines that round in different places are each that far from the truth, and at 32 layers that distance alone exceeds 8d's 2 %
         d16 = (kept[i] - r16).abs()
-        tol = 2e-2 * r16.abs().max() + 2e-2 * r16.abs() + 2 * (r16 - r32).abs().max()
-        assert (d16 <= tol).all(), (tag, d16.max().item(), tol.min().item())
-        report["steps"][tag] = {"rel_vs_fp32": _rel(kept[i], r32), "rel_bf16_oracle_vs_fp32": _rel(r16, r32), "rel_vs_bf16_oracle": _rel(kept[i], r16),
-                                "max_abs_vs_bf16_oracle": d16.max().item(), "max_abs_logit": r32.abs().max().item()}
+        tol0 = 2e-2 * r16.abs().max() + 2e-2 * r16.abs()
+        tol = tol0 + 2 * (r16 - r32).abs().max()
+        assert (d16 <= tol).all(), (what, d16.max().item(), tol.min().item())
+        report["steps"][what] = {"rel_vs_fp32": _rel(kept[i], r32), "rel_bf16_oracle_vs_fp32": _rel(r16, r32), "rel_vs_bf16_oracle": _rel(kept[i], r16),
+                                 "max_abs_vs_bf16_oracle": d16.max().item(), "max_abs_logit": r32.abs().max().item(),
+                                 "survey_8d_unwidened": {"fraction_of_logits_within": (d16 <= tol0).float().mean().item(),
+                                                         "worst_error_over_tolerance": (d16 / tol0).max().item(),
+                                                         "bf16_oracle_vs_fp32_worst_over_tolerance": ((r16 - r32).abs() / tol0).max().item()}}
+        print(f"[8B full depth {tag}] {what}: un-widened 8d tolerance met by {(d16 <= tol0).float().mean().item():.4f} of the logits, worst "
+              f"{(d16 / tol0).max().item():.2f}x the tolerance (the bf16 oracle vs fp32: {((r16 - r32).abs() / tol0).max().item():.2f}x)")
     # greedy ids: the engine's token after context i vs the fp32 oracle's argmax at the same context.  SURVEY 8d's margin (top-2 gap >
     # 1e-2 * max|logit|) was chosen for shallow stacks: after 32 layers two bf16 pipelines differ from fp32 by more than that (the bf16
     # ORACLE's own argmax flips on such rows, counted below), so a row is "confident" when its fp32 top-2 gap exceeds 3x the bf16 oracle's
@@ -269,18 +276,112 @@ def test_llama8b_full_depth_config3_parity():
     report["confident_fraction"] = confident.float().mean().item()
     report["survey_margin_rows"] = {"fraction": loose.float().mean().item(), "hip_differs": int((~same & loose).sum()),
                                     "bf16_oracle_differs": int((~same16 & loose).sum())}
-    print(f"[8B full depth] greedy agreement with the fp32 oracle: hip {report['greedy_agreement']:.3f} / bf16 oracle "
+    print(f"[8B full depth {tag}] greedy agreement with the fp32 oracle: hip {report['greedy_agreement']:.3f} / bf16 oracle "
           f"{report['greedy_agreement_bf16_oracle']:.3f} over {same.numel()} positions; confident {report['confident_fraction']:.3f}; "
           f"rows above the 1e-2 margin: hip differs on {report['survey_margin_rows']['hip_differs']}, the bf16 oracle itself on "
           f"{report['survey_margin_rows']['bf16_oracle_differs']}; oracle {oracle_s:.1f} s")
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    json.dump(report, open(os.path.join(out, "llama8b_depth_parity.json"), "w"), indent=1)
+    json.dump(report, open(os.path.join(out, report_name), "w"), indent=1)
+    oracle_argmax = s32.argmax(-1)
+    del sd_cpu, l32, l16
+    gc.collect()
+    return report, same, same16, confident, seq, oracle_argmax
+
+
+def test_llama8b_full_depth_config3_parity():
+    """BASELINE.json config 3 as SURVEY 8d specifies it, at FULL depth: SEED-LLaMA-8B (32 layers, hidden 4096, FFN 11008, vocab 40194),
+    the config-3 prompt (BOS + 8 text + <img> + 32 image codes + </img> + 16 text = T0 59), B = 4 (oracle cost; the kernels' shapes do not
+    depend on B below 64), 128 greedy decode steps through the folded-norm hipGraph path that bench.py times.  Logits at the prefill's
+    last position and at decode steps {1, 2, 64, 128} against the oracle in fp32 and in the bf16 choreography, greedy ids against the fp32
+    oracle's argmax on confident rows at EVERY one of the 129 positions (llama_xformer.py:280-332, 496-627, 661-743).
+
+    Weights: the reference's own initialiser, N(0, 0.02) everywhere (llama_xformer.py:363-372).  Its logits are nearly flat (top-2 gap
+    ~0.1 under a bf16 noise of ~0.3), so only ~1 % of the positions are confident: this run is the NOISE-FLOOR report (logit distances,
+    how often the bf16 oracle itself flips); the token evidence is test_llama8b_full_depth_peaked_logits_greedy_parity below."""
+    sd = make_llama_state_dict(C.LLAMA_8B, seed=0, device="cuda", dtype=torch.bfloat16, norm_jitter=0.05)
+    report, same, same16, confident, _, _ = _full_depth_config3(sd, "llama8b_depth_parity.json", "N(0, 0.02) weights")
     assert (same | ~confident).all(), f"{(~same & confident).sum().item()} greedy ids differ from the fp32 oracle on confident rows"
     # and the HIP path is no worse at picking the fp32 oracle's token than the oracle's own bf16 choreography (3 flips of slack)
     assert (~same).sum() <= (~same16).sum() * 1.25 + 3, ((~same).sum().item(), (~same16).sum().item())
-    del sd_cpu, l32, l16
-    gc.collect()
+
+
+def test_llama8b_full_depth_peaked_logits_greedy_parity():
+    """config 3 at full depth on a second synthetic state dict whose logits are PEAKED, so that greedy-token parity
+    is asserted on MOST of the 516 positions instead of ~1 % of them.  seed_amd.weights.make_llama_successor_state_dict: the same
+    N(0, 0.02) 32-layer body, embed_tokens ~ N(0, 1.2) and lm_head = a permutation of the embedding rows: the fp32 model emits
+    successor[last token] (a walk through the vocabulary, a different token at every step) with a top-2 gap several times the bf16
+    deviation, while attention and the MLPs still carry ~99 % of the residual stream's variance.  Asserted: at least half of the 516
+    positions are confident (fp32 top-2 gap > 3x the bf16 oracle's own largest deviation on that row), the hipGraph-replayed greedy ids
+    equal the fp32 oracle's argmax on EVERY confident position, and the fp32 oracle's argmax there is the successor the weights were
+    built for (the test knows what the right token is without trusting either pipeline)."""
+    from seed_amd.weights import make_llama_successor_state_dict
+    sd, successor = make_llama_successor_state_dict(C.LLAMA_8B, seed=0, device="cuda", dtype=torch.bfloat16, norm_jitter=0.05)
+    report, same, same16, confident, seq, oracle_argmax = _full_depth_config3(sd, "llama8b_depth_parity_peaked.json",
+                                                                              "successor weights, embed_std 1.2")
+    frac = confident.float().mean().item()
+    assert frac >= 0.5, f"only {frac:.3f} of the positions are confident: the peaked state dict is not peaked enough"
+    assert (same | ~confident).all(), f"{(~same & confident).sum().item()} greedy ids differ from the fp32 oracle on confident rows"
+    # what the fp32 oracle picks on confident rows is the successor of the last context token
+    last = seq[:, 59 - 1:59 + 128]                                                          # the token fed at each of the 129 positions
+    hit = oracle_argmax == successor.cpu()[last]
+    assert (hit | ~confident).float().mean().item() > 0.98, (hit & confident).float().mean().item()
+    assert (~same).sum() <= (~same16).sum() * 1.25 + 3, ((~same).sum().item(), (~same16).sum().item())
+    print(f"[8B full depth peaked] confident {frac:.3f}, greedy agreement {same.float().mean().item():.3f}, fp32 oracle emits the successor on "
+          f"{hit.float().mean().item():.3f} of the positions")
+
+
+def test_llama14b_width_parity_with_oracle():
+    """VERDICT r3 item 1a / BASELINE.json config 5 at its real WIDTH against the oracle: SEED-LLaMA-14B dims (LLaMA-2-13B body: hidden
+    5120, 40 heads x 128, FFN 13824, rms eps 1e-5, vocab 40194) with 2 of the 40 layers, B = 8 sequences of T = 649 built exactly as
+    bench.py's config-5 leg builds them (4 x (128 text ids, <img>, 32 image codes, </img>) after BOS;
+    gradio_demo/seed_llama_flask.py:144-150 is the interleaving, llama_xformer.py:496-627 the forward).  One prefill with the KV cache
+    written, logits of ALL 649 positions (the reference's API, llama_xformer.py:718) against O.llama_forward in fp32 and bf16 under the
+    same contract as the 8B tests; hidden 5120 / FFN 13824 hit tile counts of the 256x256 GEMM, the SwiGLU epilogue and the tiled
+    causal attention (T = 649: 5.07 query tiles) that no 8B test does.  The cache rows are compared too (they feed the decode that follows)."""
+    from dataclasses import replace
+    cfg = replace(C.LLAMA_14B, layers=2)
+    sd = make_llama_state_dict(cfg, seed=0, dtype=torch.bfloat16, norm_jitter=0.05)
+    B, T = 8, 649
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(3, 32000, (B, T), generator=g)
+    ids[:, 0] = 1
+    for r in range(4):
+        s0 = 1 + r * (128 + 34) + 128
+        ids[:, s0] = 32000 + 8192
+        ids[:, s0 + 1:s0 + 33] = 32000 + torch.randint(0, 8192, (B, 32), generator=g)
+        ids[:, s0 + 33] = 32000 + 8193
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=704, decode_packed=False)      # as bench.py's leg constructs it
+    logits = eng.forward(ids.cuda())
+    torch.cuda.synchronize()
+    assert tuple(logits.shape) == (B, T, cfg.vocab)
+    last = eng.forward(ids.cuda(), past_len=0, last_only=True)                              # the leg bench.py times: last position only
+    torch.cuda.synchronize()
+    assert torch.equal(last[:, 0], logits[:, -1]), "last_only prefill differs from the all-positions prefill"
+    l32, p32 = O.llama_forward(sd, cfg, ids, mode="fp32")
+    l16, p16 = O.llama_forward(sd, cfg, ids, mode="bf16")
+    _check_logits(logits, l32, l16, "14B-width prefill, all 649 positions")
+    for pos in (0, 128, 161, 162, 648):                      # BOS, <img>, last image code, </img>, last position
+        _check_logits(logits[:, pos], l32[:, pos], l16[:, pos], f"14B-width prefill position {pos}")
+    for layer in (0, 1):
+        ek, ek16 = _rel(eng.k_cache[layer][:B, :, :T].float(), p32[layer][0]), _rel(p16[layer][0], p32[layer][0])
+        ev, ev16 = _rel(eng.v_cache[layer][:B, :, :T].float(), p32[layer][1]), _rel(p16[layer][1], p32[layer][1])
+        print(f"[14B-width layer {layer}] keys rel vs fp32 oracle: hip {ek:.3e} / bf16-oracle {ek16:.3e}; values {ev:.3e} / {ev16:.3e}")
+        assert ek < max(1.5 * ek16, 5e-3) and ev < max(1.5 * ev16, 5e-3), (layer, ek, ek16, ev, ev16)
+    # greedy next token of every position vs the fp32 oracle on confident rows (same definition as the 8B width test)
+    top2 = l32.topk(2, dim=-1).values
+    gap = top2[..., 0] - top2[..., 1]
+    confident = (gap > 1e-2 * l32.abs().amax(-1)) & (gap > 3.0 * (l16 - l32).abs().amax(-1))
+    same = logits.float().cpu().argmax(-1) == l32.argmax(-1)
+    assert (same | ~confident).all(), f"{(~same & confident).sum().item()} argmax ids differ on confident positions"
+    print(f"[14B-width] argmax agreement {same.float().mean().item():.3f}, confident {confident.float().mean().item():.3f}")
+    # one cached decode step on top of the prefill (M = 8: the weight-streaming path at K = 5120 / 13824 on row-major weights)
+    tok = l32[:, -1].argmax(-1, keepdim=True)
+    a32, _ = O.llama_forward(sd, cfg, tok, past=p32, mode="fp32")
+    a16, _ = O.llama_forward(sd, cfg, tok, past=p16, mode="bf16")
+    step = eng.forward(tok.cuda(), last_only=True)
+    torch.cuda.synchronize()
+    _check_logits(step[:, 0], a32[:, -1], a16[:, -1], "14B-width decode step 1")
 
 
 def test_persistent_decode_layers_are_bit_identical():
@@ -403,3 +504,68 @@ def test_llama8b_full_size_properties():
     sub = eng.greedy_decode_graph(prompt[7:12].contiguous(), n_new)
     torch.cuda.synchronize()
     assert torch.equal(sub, graphed[7:12])
+
+
+def test_split_k_error_word_is_sticky_and_reported():
+    """the split-K decode GEMM records a partner that never arrived in the last flag word of its workspace.  The per-step
+    clear must leave that word alone (it used to zero it with the hand-off flags), seedmi_llama_decode_status must report it after the
+    loop, clear it once reported, and a healthy loop must report nothing."""
+    import ctypes as Ct
+    from dataclasses import replace
+    from seed_amd import lib as L
+    cfg = replace(C.LLAMA_8B, layers=1)
+    sd = make_llama_state_dict(cfg, seed=1, dtype=torch.bfloat16)
+    B = 4
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=64)
+    prompt = torch.randint(3, 32000, (B, 7), generator=torch.Generator().manual_seed(1)).cuda()
+    toks = eng.greedy_decode_graph(prompt, 5)                               # ends with decode_status(): healthy -> no error
+    torch.cuda.synchronize()
+    ws = eng._ws
+    # poison the sticky word the way a timed-out owner would (1 + blockIdx), run more steps, and the status call must still see it
+    sk_words = 1024
+    total = eng.lib.seedmi_llama_workspace_bytes(Ct.byref(eng.w), B, 1)
+    word = None
+    view = ws[:total].view(torch.int32)
+    # locate the split-K area: seedmi_llama_decode_status reads it, so probe candidate positions through the API instead of
+    # restating the carve: set a word, ask, and keep the position that reports
+    for off in range(0, total // 4 - sk_words, 64):                          # carve offsets are 256-byte aligned
+        view[off + sk_words - 1] = 7
+        rc = eng.lib.seedmi_llama_decode_status(Ct.byref(eng.w), B, L.ptr(ws), ws.numel(), L.stream_ptr())
+        if rc != 0:
+            word = off + sk_words - 1
+            assert "workgroup 6" in eng.lib.seedmi_last_error().decode()
+            break
+        view[off + sk_words - 1] = 0
+    assert word is not None, "no split-K area found in the decode workspace"
+    assert eng.lib.seedmi_llama_decode_status(Ct.byref(eng.w), B, L.ptr(ws), ws.numel(), L.stream_ptr()) == 0     # cleared once reported
+    view[word] = 3
+    tok = toks[:, -1:].contiguous()
+    for _ in range(3):
+        eng.forward(tok, last_only=True)                                    # each step clears the hand-off flags, NOT the error word
+    torch.cuda.synchronize()
+    assert int(view[word]) == 3
+    with pytest.raises(L.SeedmiError, match="gave up waiting"):
+        eng.decode_status(B)
+    eng.decode_status(B)
+
+
+def test_padded_attention_mask_warns(tmp_path):
+    """VERDICT r3 weak 12 / SURVEY H7: padding masks are not applied (the reference's xformers path ignores them too); a mask that
+    contains zeros now says so instead of silently answering for padding.  A mask of ones stays silent."""
+    import warnings as W
+    from models.llama_xformer import LlamaForCausalLM
+    from transformers.models.llama.configuration_llama import LlamaConfig as HFConfig
+    cfg = C.LLAMA_TINY
+    hf = HFConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.ffn, num_hidden_layers=cfg.layers,
+                  num_attention_heads=cfg.heads, rms_norm_eps=cfg.rms_eps, max_position_embeddings=cfg.max_pos)
+    model = LlamaForCausalLM(hf)
+    model.load_state_dict(make_llama_state_dict(cfg, seed=2), strict=True)
+    model = model.eval().to("cuda")
+    ids = torch.randint(3, cfg.vocab, (2, 6), generator=torch.Generator().manual_seed(0)).cuda()
+    with W.catch_warnings():
+        W.simplefilter("error")
+        model(input_ids=ids, attention_mask=torch.ones_like(ids))
+    mask = torch.ones_like(ids)
+    mask[1, :2] = 0
+    with pytest.warns(RuntimeWarning, match="padding masks are not applied"):
+        model(input_ids=ids, attention_mask=mask)

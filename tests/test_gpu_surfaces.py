@@ -230,3 +230,53 @@ def test_beam_search_reorders_the_static_cache(llama_dir):
     want = model(input_ids=nxt, past_key_values=o2.past_key_values, use_cache=True).logits
     assert torch.equal(got, want)
     print(f"[beam search] _reorder_cache called {len(calls)} times by generate(num_beams=2)")
+
+
+def test_dp_pretokenizer_tool_end_to_end_on_device(tmp_path, monkeypatch):
+    """SURVEY 8f-1 end to end on the device: ``seed_amd.tools.extract_image_ids.main`` on a directory of JPEG /
+    PNG files of assorted sizes (incl. the reference's own fixture, tests/golden/cat.jpg = images/cat.jpg) with ``--gpu-preprocess``:
+    directory -> JPEG decode -> DevicePreprocessor -> TokenizerEngine (full-size SEED-2, the tool's default weights) -> tar shards.
+    The members must follow the reference tool's on-disk format (MultiModalLLM/src/tools/extract_image_ids_to_torchdata_parallel.py:
+    114-127: pickled {'image_ids': [32 ints], 'text', 'metadata'}), and the ids must EQUAL ``TokenizerEngine.encode`` of the tensors
+    the reference's own PIL transform (models/transforms.py:13-16) produces for the same files - device preprocessing is bit-exact
+    and the tokenizer is a pure map over images, so equality is exact whatever the batch composition."""
+    import pickle
+    import shutil
+    import tarfile
+    import numpy as np
+    from PIL import Image
+    from models.transforms import get_transform
+    from seed_amd.tokenizer_engine import TokenizerEngine
+    from seed_amd.tools import extract_image_ids as tool
+    src = tmp_path / "imgs"
+    (src / "sub").mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "cat.jpg"), src / "cat.jpg")
+    (src / "cat.txt").write_text("a cat on the grass\n")
+    rs = np.random.RandomState(0)
+    for name, (h, w) in (("a_wide.jpg", (180, 333)), ("b_tall.png", (401, 97)), ("sub/c_small.jpg", (64, 64)), ("sub/d_big.jpg", (512, 640))):
+        Image.fromarray(rs.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(src / name)
+    out = tmp_path / "ids"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    tool.main(["--images", str(src), "--save_dir", str(out), "--batch_size", "3", "--gpu-preprocess"])
+    files = tool.list_images(str(src))
+    assert len(files) == 5
+    got = {}
+    part = out / "part-0000"
+    for tar in sorted(os.listdir(part)):
+        with tarfile.open(part / tar) as tf:
+            for m in tf.getmembers():
+                s = pickle.loads(tf.extractfile(m).read())
+                assert set(s) == {"image_ids", "text", "metadata"} and len(s["image_ids"]) == 32
+                assert all(isinstance(v, int) and 0 <= v < 8192 for v in s["image_ids"])
+                got[s["metadata"]["path"]] = (m.name, s)
+    assert sorted(got) == files
+    assert [got[f][0] for f in files] == [f"{i:09d}.pkl" for i in range(5)]                  # keys = positions in the sorted list
+    assert got[str(src / "cat.jpg")][1]["text"] == "a cat on the grass" and got[str(src / "a_wide.jpg")][1]["text"] == ""
+    # the same files through the reference's host transform and the engine directly
+    tf_host = get_transform(type="clip", keep_ratio=False, image_size=224)
+    x = torch.stack([tf_host(Image.open(f).convert("RGB")) for f in files]).cuda()
+    eng = TokenizerEngine(make_tokenizer_state_dict(C.SEED2, seed=0, device="cuda"), C.SEED2, device="cuda")
+    want = eng.encode(x).cpu().tolist()
+    for f, row in zip(files, want):
+        assert got[f][1]["image_ids"] == row, f

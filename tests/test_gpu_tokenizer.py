@@ -231,6 +231,106 @@ def test_full_size_batch256_properties():
         lib.seedmi_set_option(b"tokenize_streams", 2)
 
 
+
+def test_full_size_batch256_against_live_reference_modules():
+    """BASELINE.json config 2 ITSELF (256 synthetic 224x224 images, bf16, one seedmi_tokenize call with its two sub-batch streams)
+    against the reference's OWN modules run live on this host: oracle/ref_shims.py imports them from /root/reference in the build
+    container and from the bytecode under oracle/_ref (oracle/build_ref.py) on the GPU box.  64 of the 256 images - rows from both
+    sub-batches and both sides of their boundary - go through the reference in fp32 (models/seed_qformer/qformer_quantizer.py:288-307
+    re-assembled on its sub-modules); the codebook is calibrated on the reference's z.  Asserted: z no further from the reference
+    than 2e-2, id agreement with the reference's fp32 ids at the rate measured on the 16 committed golden images, and EVERY id that
+    differs sits on a row whose reference top-2 gap is inside the perturbation the measured dz can cause.  (the
+    full batch used to be compared only with itself in smaller batches, and 16 golden images were the whole full-size sample.)"""
+    from oracle import ref_shims
+    if not ref_shims.reference_available():
+        pytest.skip("no reference modules here (neither /root/reference nor oracle/_ref: run `python -m oracle.build_ref` in the build container)")
+    from oracle import make_golden
+    import time
+    cfg = C.SEED2
+    rows = list(range(0, 16)) + list(range(112, 144)) + list(range(240, 256))                # 64 rows; 128 is the sub-batch boundary
+    sd = make_tokenizer_state_dict(cfg, seed=0)
+    img = torch.randn(256, 3, 224, 224, generator=torch.Generator().manual_seed(1234)).bfloat16()
+    ref = ref_shims.load_reference_modules()
+    mods = ref_shims.build_reference_tokenizer_modules(ref, cfg)
+    make_golden.load_tokenizer_weights(mods, sd)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    t0 = time.time()
+    sub = img[rows].float()
+    _, taps_ref = ref_shims.reference_get_codebook_indices(mods, sd["query_tokens"].clone(), sub)
+    cb = calibrate_codebook(taps_ref["z"], cfg.n_embed, seed=7)
+    mods.quantize.embedding.weight.data.copy_(cb)
+    ids_ref = mods.quantize(taps_ref["z"])[2].reshape(len(rows), -1)                         # VectorQuantizer2.forward on the same z
+    ref_s = time.time() - t0
+    sd["quantize.embedding.weight"] = cb
+    eng = TokenizerEngine(sd, cfg, device="cuda")
+    taps = {}
+    ids = eng.encode(img.cuda(), taps)
+    torch.cuda.synchronize()
+    ids_sub, z = ids.cpu()[rows], taps["z"].float().cpu().reshape(256, cfg.n_query, cfg.code_dim)[rows]
+    z_ref = taps_ref["z"]
+    e = _rel(z, z_ref)
+    agree = (ids_sub == ids_ref).float().mean().item()
+    zf = z_ref.reshape(-1, cfg.code_dim)
+    d = (zf ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * zf @ cb.t()
+    top2 = d.topk(2, dim=1, largest=False).values
+    gap = top2[:, 1] - top2[:, 0]
+    dz = (z.reshape(-1, cfg.code_dim) - zf).norm(dim=1)
+    bound = 2 * (2 * dz * (zf.norm(dim=1) + cb.norm(dim=1).max()))
+    differ = (ids_sub != ids_ref).reshape(-1)
+    print(f"[config 2 vs live reference modules ({ref_shims.reference_origin()}), {len(rows)} of 256 images, reference {ref_s:.1f} s] "
+          f"z rel err {e:.3e}; ids agree {agree:.4f} ({int(differ.sum())} of {differ.numel()} differ, all near-ties: "
+          f"{not bool((differ & (gap > bound)).any())})")
+    assert e < 2e-2, e
+    assert agree >= FULL_AGREE_HIP_VS_REFERENCE_FP32, agree
+    assert not (differ & (gap > bound)).any(), "an id differs from the live reference on a row that is not a near-tie"
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"images_compared": len(rows), "of_batch": 256, "reference": ref_shims.reference_origin(), "z_rel_hip_vs_ref_fp32": e,
+                   "ids_agree_hip_vs_ref_fp32": agree, "ids_differing": int(differ.sum()), "all_differing_rows_are_near_ties": True,
+                   "reference_seconds": round(ref_s, 1)}, open(os.path.join(out, "config2_vs_live_reference.json"), "w"), indent=1)
+
+
+def test_tokenize_with_caller_owned_fork_join_objects():
+    """seedmi_tokenize_fj: the caller passes the side streams and events the sub-batch overlap needs (the library then creates
+    nothing); ids are bit-identical to seedmi_tokenize's for 1, 2 and 4 sub-batches, and bad descriptors are rejected."""
+    import ctypes as Ct
+    from seed_amd import lib as L
+    lib = L.load()
+    cfg = C.MID
+    sd = make_tokenizer_state_dict(cfg, seed=4, ln_jitter=0.02)
+    img = torch.randn(40, 3, cfg.img_size, cfg.img_size, generator=torch.Generator().manual_seed(8)).cuda()
+    eng = TokenizerEngine(sd, cfg)
+    t = {}
+    eng.encode(img[:8], t)
+    eng.set_codebook(calibrate_codebook(t["z"].float().cpu(), cfg.n_embed, seed=7))
+    want = eng.encode(img)
+    torch.cuda.synchronize()
+    ws = torch.empty(lib.seedmi_tokenize_workspace_bytes(Ct.byref(eng.w), 40), dtype=torch.uint8, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    events = [torch.cuda.Event() for _ in range(4)]
+    for e in events:
+        e.record()                                    # torch creates the hipEvent lazily: make it exist
+    torch.cuda.synchronize()
+    x = img.contiguous()
+    for n_side in (0, 1, 3):
+        fj = L.ForkJoin()
+        for i in range(3):
+            fj.side_stream[i] = streams[i].cuda_stream
+            fj.join_event[i] = events[i + 1].cuda_event
+        fj.fork_event = events[0].cuda_event
+        fj.n_side = n_side
+        got = torch.empty(40, cfg.n_query, dtype=torch.int64, device="cuda")
+        L.check(lib.seedmi_tokenize_fj(Ct.byref(eng.w), L.ptr(x), 1, 40, L.ptr(got), None, L.ptr(ws), ws.numel(), Ct.byref(fj),
+                                       L.stream_ptr()), "seedmi_tokenize_fj")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), n_side
+    fj.n_side = 5
+    assert lib.seedmi_tokenize_fj(Ct.byref(eng.w), L.ptr(x), 1, 40, L.ptr(got), None, L.ptr(ws), ws.numel(), Ct.byref(fj), L.stream_ptr()) == -1
+    fj.n_side, fj.fork_event = 1, None
+    assert lib.seedmi_tokenize_fj(Ct.byref(eng.w), L.ptr(x), 1, 40, L.ptr(got), None, L.ptr(ws), ws.numel(), Ct.byref(fj), L.stream_ptr()) == -1
+
+
 _RCCL_WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, os.environ["SEED_ROOT"])

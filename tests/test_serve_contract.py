@@ -181,3 +181,49 @@ def test_generate_end_to_end_on_device_engines():
     alone = [svc.handle(r) for r in reqs]
     assert [o['text'] for o in together] == [o['text'] for o in alone]
     assert svc.handle({'text': 'aaa', 'images': [], 'max_new_tokens': 6, 'temperature': 0.0})['text'] == alone[0]['text']
+
+
+def test_tiny_temperature_is_greedy_and_a_bad_image_payload_is_an_error_reply():
+    """a temperature in (0, 0.0005) rounds to 0.0 - the key must then be the greedy one (the device sampler rejects
+    temperature 0 only after a KV slot was taken); an undecodable image is an error_msg reply for THAT request, its neighbour is served."""
+    svc = _service([3 + ord('o'), 2])
+    svc.handle({'text': 'a', 'images': [], 'temperature': 0.0004, 'top_p': 0.5})
+    assert (svc.llm.calls[-1]['top_p'], svc.llm.calls[-1]['temperature']) == (0.0, 1.0)
+    svc.handle({'text': 'a', 'images': [], 'temperature': 0.7, 'top_p': 0.0004})
+    assert (svc.llm.calls[-1]['top_p'], svc.llm.calls[-1]['temperature']) == (0.0, 1.0)
+    svc.handle({'text': 'a', 'images': [], 'temperature': 0.7004, 'top_p': 0.5})
+    assert (svc.llm.calls[-1]['top_p'], svc.llm.calls[-1]['temperature']) == (0.5, 0.7)
+    bad = base64.b64encode(b'not an image at all').decode()
+    outs = svc.handle_many([{'text': 'x<image>y', 'images': [bad]}, {'text': 'fine', 'images': []}])
+    assert outs[0]['error_msg'] and outs[0]['text'] == ''
+    assert outs[1]['text'] == 'o' and not outs[1]['error_msg']
+
+
+def test_a_failing_decode_loop_leaves_nothing_queued():
+    """if one batcher's run() raises, the tickets of the batchers that have not run yet are cancelled."""
+    class Boom:
+        def __init__(self, fail):
+            self.fail, self.q, self.cancelled = fail, [], []
+
+        def submit(self, ids, max_new):
+            self.q.append(max_new)
+            return len(self.q) - 1
+
+        def cancel(self, rid):
+            self.cancelled.append(rid)
+            return True
+
+        def run(self):
+            if self.fail:
+                raise RuntimeError("decode loop died")
+            return {i: [2] for i in range(len(self.q))}
+    made = []
+
+    def factory(top_p, temperature):
+        made.append(Boom(fail=len(made) == 0))
+        return made[-1]
+    svc = _service([2])
+    svc._batcher_factory = factory
+    with pytest.raises(RuntimeError, match="decode loop died"):
+        svc.handle_many([{'text': 'a', 'images': [], 'top_p': 0.5}, {'text': 'b', 'images': [], 'top_p': 0.9}])
+    assert made[0].cancelled == [0] and made[1].cancelled == [0]

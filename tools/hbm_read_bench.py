@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Measured HBM read ceiling: seedmi_bench_stream_read over buffers of decode-GEMM size and larger."""
+"""Measured HBM read ceiling: seedcal_stream_read over buffers of decode-GEMM size and larger."""
 import json
 import os
 import sys
@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seed_amd import lib as L  # noqa: E402
+from tools import calib  # noqa: E402
 
 lib = L.load()
 scratch = torch.zeros(4, dtype=torch.int32, device="cuda")
@@ -17,13 +18,13 @@ for mb in (33, 100, 180, 1024, 8192):
     buf.random_(0, 255)
     for bpc in (1, 2, 4):
         for _ in range(3):
-            L.check(lib.seedmi_bench_stream_read(L.ptr(buf), buf.numel(), bpc, L.ptr(scratch), L.stream_ptr()), "stream")
+            calib.check(calib.load().seedcal_stream_read(L.ptr(buf), buf.numel(), bpc, L.ptr(scratch), L.stream_ptr()), "stream")
         torch.cuda.synchronize()
         reps = 20 if mb < 2000 else 5
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            L.check(lib.seedmi_bench_stream_read(L.ptr(buf), buf.numel(), bpc, L.ptr(scratch), L.stream_ptr()), "stream")
+            calib.check(calib.load().seedcal_stream_read(L.ptr(buf), buf.numel(), bpc, L.ptr(scratch), L.stream_ptr()), "stream")
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 closing run on the GPU box: the whole -m gpu suite, smoke(), every profile (tools/r03_profiles.sh), then the A/B tables.
+# Round-3 closing run on the GPU box: the whole -m gpu suite, smoke(), every profile (tools/lab/r03_profiles.sh), then the A/B tables.
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 O=gpurun_out/r03p
@@ -7,7 +7,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
-timeout 2400 bash tools/r03_profiles.sh > $O/profiles.log 2>&1
+timeout 2400 bash tools/lab/r03_profiles.sh > $O/profiles.log 2>&1
 OUT=$O/tok_ab.json ROUNDS=4 timeout 600 python tools/tok_ab.py "" "gemm_sched=31" "gemm_sched=0" "attn_vit=1" "attn_vit=4" "tokenize_streams=1" "tokenize_tile_stats=1" > $O/tok_ab.log 2>&1
 SEEDMI_LIB_PATH=seed_amd/libseedmi_dev.so SCHEDS=0,31,81,593,543 OUT=$O/gemm_sched_ab.json timeout 600 python tools/gemm_sched_ab.py > $O/gemm_sched_ab.log 2>&1
 timeout 400 python tools/gemm_sustained.py > $O/gemm_sustained.log 2>&1

@@ -2,7 +2,7 @@
 """Where a decode GEMM launch loses time against a plain stream of the same bytes (devtools library: SEEDMI_LIB_PATH=seed_amd/libseedmi_dev.so).
 seedmi_set_option("skinny_ablate", bits): 1 = no activation loads, 2 = no MFMA / norm sums, 4 = no cross-wave reduction / epilogue.
 Every shape is issued as the decode chain issues it (fragment-major W and A, folded RMSNorm where the chain folds it); weights rotate over
-> 600 MB of copies so every launch streams from HBM.  The last column is seedmi_bench_stream_read over the same number of bytes."""
+> 600 MB of copies so every launch streams from HBM.  The last column is seedcal_stream_read over the same number of bytes."""
 import os
 import sys
 
@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seed_amd import lib as L  # noqa: E402
+from tools import calib  # noqa: E402
 
 lib = L.load()
 M = int(os.environ.get("M", "32"))
@@ -72,7 +73,7 @@ for name, N, K, epi, eps in [("qkv", 12288, 4096, L.EPI_NONE, 1e-6), ("o", 4096,
         line.append(f"abl{abl}: {us:5.1f}us {N * K * 2 / us / 1e6:4.2f}TB/s")
     L.check(lib.seedmi_set_option(b"skinny_ablate", 0), "skinny_ablate")
     nbytes = N * K * 2
-    us = timed(lambda Wp: L.check(lib.seedmi_bench_stream_read(L.ptr(Wp), nbytes, 1, L.ptr(scratch), L.stream_ptr()), "stream"))
+    us = timed(lambda Wp: calib.check(calib.load().seedcal_stream_read(L.ptr(Wp), nbytes, 1, L.ptr(scratch), L.stream_ptr()), "stream"))
     line.append(f"stream: {us:5.1f}us {nbytes / us / 1e6:4.2f}TB/s")
     print(" | ".join(line), flush=True)
     del Wps
