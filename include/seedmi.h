@@ -386,6 +386,10 @@ typedef struct {
                                       * post_attention_layernorm, model.norm): decode steps then run without norm launches */
 } seedmi_llama_weights_t;
 
+/* The first seedmi_gemm_skinny_workspace_bytes() bytes of a workspace (whatever batch and T it was sized for) are the split-K area of
+ * seedmi_gemm_skinny_norm_ws_bf16, used by decode steps (T == 1, batch <= 32): ZERO the workspace once after allocation (hipMemset) -
+ * every step clears its hand-off flags itself, the sticky error word (32-bit word 1023) is only ever cleared by seedmi_llama_decode_status;
+ * prefills never touch the area, so one workspace may serve prefills and decode steps alike. */
 size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, int batch, int T);
 /* LlamaForCausalLM.forward, eval, use_cache (llama_xformer.py:661-743): ids/pos int64 [B,T]; appends to the static
  * KV cache at past_len; logits bf16 [B*T_out, ldl] where T_out = T (all positions, reference behaviour) or 1

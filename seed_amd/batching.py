@@ -37,7 +37,7 @@ class ContinuousBatcher:
         self.uniforms = torch.zeros(self.chunk, self.B, dtype=torch.float32, device=dev) if top_p > 0.0 else None
         self.logits = torch.empty(self.B, engine.vocab_pad, dtype=torch.bfloat16, device=dev)
         # the step's workspace is baked into the captured graph: owned here, never reallocated; prefills use their own
-        self._ws = torch.empty(self.lib.seedmi_llama_workspace_bytes(C.byref(engine.w), self.B, 1), dtype=torch.uint8, device=dev)
+        self._ws = torch.zeros(self.lib.seedmi_llama_workspace_bytes(C.byref(engine.w), self.B, 1), dtype=torch.uint8, device=dev)
         self._ws_prefill = None
         self._graph = None
         self._slot_w = {}
@@ -81,7 +81,7 @@ class ContinuousBatcher:
             else:
                 req["max_new"] = min(req["max_new"], room)
         self._graph, self._slot_w = None, {}
-        self._ws = torch.empty(self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), self.B, 1), dtype=torch.uint8, device=eng.device)
+        self._ws = torch.zeros(self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), self.B, 1), dtype=torch.uint8, device=eng.device)
         self._ws_prefill = None
         self._generation = eng.cache_generation
 

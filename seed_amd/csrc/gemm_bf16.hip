@@ -864,6 +864,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr bool LATEWAIT = (SCHED & 2048) != 0;
     bool tile_ragged = false;
     static_assert(!TWOPH || (SCHED & 14) == 0, "the two-phase schedule has its own request placement");
+    // (round 4: the branch form of the split inside the two-phase K-tile - phase a on every wave's own 64 x 64 block, phase b empty in a
+    // ragged tile - compiled without scratch (252 VGPRs) and measured -1.7 .. -2.3 % on every shape, fc1 - which has no ragged tile - included:
+    // the wave-uniform branches around phase b's reads and MFMAs cost every tile more than the ragged tiles return; 122.7 vs 120.9 ms per
+    // tokenize pass, profiles/r04_call3_ragged_split_two_phase.log.  Removed again.)
     static_assert(!(TWOPH && RAGSPLIT), "the ragged-tile split lives in the four-phase K-tile body");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1718,6 +1722,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
 #ifdef SEEDMI_DEVTOOLS
     if (LNF) return (variant == 128) ? launch_gemm128<EPI, LNF>(p, s) : launch_gemm256<EPI, LNF>(p, s, sk_ws, sk_ws_bytes);
     if (variant == 257 && EPI != EPI_SWIGLU && EPI != EPI_PATCH_EMBED) return launch_gemm256k<EPI>(p, s, sk_ws, sk_ws_bytes);
+    if (variant == 233 && EPI != EPI_SWIGLU && EPI != EPI_PATCH_EMBED) return launch_gemm256t<EPI>(p, s, sk_ws, sk_ws_bytes);   // two-phase K-tile on 32x32x16
     if (variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
     if (variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
 #endif
@@ -1739,7 +1744,7 @@ static int auto_group_m(int N, int K) {
 
 extern "C" int seedmi_set_option(const char* key, int value) {
 #ifdef SEEDMI_DEVTOOLS
-    const bool dev_variant = value == 232 || value == 255 || value == 257;
+    const bool dev_variant = value == 232 || value == 233 || value == 255 || value == 257;
 #else
     const bool dev_variant = false;
 #endif

@@ -1201,6 +1201,10 @@ LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     const size_t Mp = (M + 15) / 16 * 16;            // fragment-major buffers hold whole 16-row tiles
     Carver c(ws);
     LlamaWs t;
+    // split-K decode GEMMs: flag words + fp32 images of the cut tiles.  FIRST and at the same offset for every (B, T): a workspace that
+    // serves prefills and decode steps alike (LlamaEngine's) must not have a prefill's activations land on the flag words - the sticky
+    // error word among them is cleared by nobody but seedmi_llama_decode_status (zeroed once by the caller after allocation)
+    void* const sk_area = c.take(SK2_WS_BYTES);
     t.x = (bf16_t*)c.take(M * h * 2);
     t.xn = (bf16_t*)c.take(Mp * h * 2);
     t.qkv = (bf16_t*)c.take(M * 3 * h * 2);
@@ -1208,7 +1212,7 @@ LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     t.att = (bf16_t*)c.take(Mp * h * 2);
     t.act = (bf16_t*)c.take(Mp * F * 2);
     t.bar = (unsigned*)c.take(256);                  // persistent decode kernel: arrival counter, error flag
-    t.sk = (T == 1 && M <= 32) ? c.take(SK2_WS_BYTES) : nullptr;      // split-K decode GEMMs: flag words + fp32 images of the cut tiles
+    t.sk = (T == 1 && M <= 32) ? sk_area : nullptr;
     // ... and its per-layer activation buffers (qkv | att | xn after o_proj | act | xn after down), decode steps only: a buffer that
     // is written once per launch never has a stale copy in another XCD's L2, so no phase needs a cache invalidate
     t.mega_stride = 0;

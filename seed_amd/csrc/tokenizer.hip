@@ -376,14 +376,6 @@ extern "C" int seedmi_tokenize_fj(const seedmi_tokenizer_weights_t* w, const voi
                          w->img_size, w->patch, w->vit_dim, w->vit_heads, w->qf_dim, w->qf_heads);
         return SEEDMI_E_SHAPE;
     }
-    const size_t need = caller_fj ? ws_for(w, batch, batch >= SPLIT_MIN_BATCH ? caller_fj->n_side + 1 : 1) : total_ws(w, batch);
-    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) {
-        seedmi_set_error("seedmi_tokenize: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
-        return SEEDMI_E_ALIGN;
-    }
-    const int grid = w->img_size / w->patch;
-    const size_t NT = (size_t)grid * grid + 1;
-    const size_t img_bytes = (size_t)3 * w->img_size * w->img_size * (images_fp32 ? 4 : 2);
     // caller-owned fork/join objects decide the number of sub-batches themselves (n_side + 1); the library's own set follows the option
     int nparts = n_parts(batch);
     if (caller_fj) {
@@ -402,6 +394,14 @@ extern "C" int seedmi_tokenize_fj(const seedmi_tokenizer_weights_t* w, const voi
                 return SEEDMI_E_SHAPE;
             }
     }
+    const size_t need = ws_for(w, batch, nparts);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) {
+        seedmi_set_error("seedmi_tokenize: workspace %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, need);
+        return SEEDMI_E_ALIGN;
+    }
+    const int grid = w->img_size / w->patch;
+    const size_t NT = (size_t)grid * grid + 1;
+    const size_t img_bytes = (size_t)3 * w->img_size * w->img_size * (images_fp32 ? 4 : 2);
     const bool split = nparts > 1;
     Part parts[MAX_PARTS];
     int b_begin = 0;

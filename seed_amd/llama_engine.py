@@ -125,7 +125,9 @@ class LlamaEngine:
         # sized by what the library asks for THIS shape (a decode step carves regions a prefill does not: B * T alone does not order them)
         nbytes = self.lib.seedmi_llama_workspace_bytes(C.byref(self.w), B, T)
         if self._ws is None or nbytes > self._ws.numel():
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            # ZEROED once at allocation (include/seedmi.h): the split-K flag words must start at zero and the sticky error word among
+            # them is never cleared by a decode step
+            self._ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
             self._ws_key = (B, T)
         return self._ws
 

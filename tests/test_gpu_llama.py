@@ -357,7 +357,8 @@ def test_llama14b_width_parity_with_oracle():
     assert tuple(logits.shape) == (B, T, cfg.vocab)
     last = eng.forward(ids.cuda(), past_len=0, last_only=True)                              # the leg bench.py times: last position only
     torch.cuda.synchronize()
-    assert torch.equal(last[:, 0], logits[:, -1]), "last_only prefill differs from the all-positions prefill"
+    # (the last-position lm_head runs on the weight-streaming kernel, M = 8: another fp32 summation order than the MFMA tile's)
+    assert _rel(last[:, 0].float(), logits[:, -1].float()) < 5e-3, "last_only prefill differs from the all-positions prefill"
     l32, p32 = O.llama_forward(sd, cfg, ids, mode="fp32")
     l16, p16 = O.llama_forward(sd, cfg, ids, mode="bf16")
     _check_logits(logits, l32, l16, "14B-width prefill, all 649 positions")
@@ -521,22 +522,14 @@ def test_split_k_error_word_is_sticky_and_reported():
     toks = eng.greedy_decode_graph(prompt, 5)                               # ends with decode_status(): healthy -> no error
     torch.cuda.synchronize()
     ws = eng._ws
-    # poison the sticky word the way a timed-out owner would (1 + blockIdx), run more steps, and the status call must still see it
-    sk_words = 1024
-    total = eng.lib.seedmi_llama_workspace_bytes(Ct.byref(eng.w), B, 1)
-    word = None
-    view = ws[:total].view(torch.int32)
-    # locate the split-K area: seedmi_llama_decode_status reads it, so probe candidate positions through the API instead of
-    # restating the carve: set a word, ask, and keep the position that reports
-    for off in range(0, total // 4 - sk_words, 64):                          # carve offsets are 256-byte aligned
-        view[off + sk_words - 1] = 7
-        rc = eng.lib.seedmi_llama_decode_status(Ct.byref(eng.w), B, L.ptr(ws), ws.numel(), L.stream_ptr())
-        if rc != 0:
-            word = off + sk_words - 1
-            assert "workgroup 6" in eng.lib.seedmi_last_error().decode()
-            break
-        view[off + sk_words - 1] = 0
-    assert word is not None, "no split-K area found in the decode workspace"
+    # poison the sticky word the way a timed-out owner would (1 + blockIdx): the split-K area is the FIRST part of the workspace
+    # (include/seedmi.h), its flag words come first and the error word is the last of the 1024
+    view = ws.view(torch.int32)
+    word = 1023
+    assert int(view[word]) == 0
+    view[word] = 7
+    assert eng.lib.seedmi_llama_decode_status(Ct.byref(eng.w), B, L.ptr(ws), ws.numel(), L.stream_ptr()) != 0
+    assert "workgroup 6" in eng.lib.seedmi_last_error().decode()
     assert eng.lib.seedmi_llama_decode_status(Ct.byref(eng.w), B, L.ptr(ws), ws.numel(), L.stream_ptr()) == 0     # cleared once reported
     view[word] = 3
     tok = toks[:, -1:].contiguous()
