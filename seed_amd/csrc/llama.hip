@@ -601,6 +601,13 @@ __global__ __launch_bounds__(512, WGS == 2 ? 4 : 1) void gemm_skinny_sk_kernel(c
 // where the shape divides, cut otherwise (see launch_skinny_sk); 2 = this kernel, always cut (R = 4); 3 = this kernel only where the round-1
 // form's last round of workgroups would be under 95 % full (8B: gate/up, 2.69 rounds - 45.4 -> 35.6 us), the round-1 kernel elsewhere
 std::atomic<int> g_skinny_sk{1};
+// seedmi_set_option("prefill_streamk", 0|1|2): stream-K tail for the prefill's MFMA GEMMs - 0 off (default), 1 every GEMM, 2 only the GEMMs
+// whose data-parallel walk is short and ends in a badly filled round (< 3 rounds of 256x256 tiles, the last one under 75 % full: o_proj and
+// down at 8 x 649 tokens of 14B are 1.64 rounds).  Measured at that shape (profiles/r04_call4_prefill_streamk.log,
+// r04_call5_prefill_streamk_selective.log): 107.9 / 112.0 ms without, 117.2 ms with 2, 124.9 / 127.0 ms with 1 - the hand-off (a 256 KiB
+// fp32 image written through and read back per shared tile, a pipeline refill per segment) costs more than the badly filled round wastes,
+// for the short GEMMs too.  Bit-identical logits in every mode.
+std::atomic<int> g_prefill_streamk{0};
 
 // best fill of the last round of workgroups over the row-tile counts launch_skinny_nw may pick (R = 1..3)
 bool skinny_rounds_underfilled(int M, int N) {
@@ -1195,7 +1202,7 @@ __global__ __launch_bounds__(512) void decode_layers_kernel(const MegaParams p) 
 std::atomic<int> g_decode_mega{0};               // seedmi_set_option("decode_persistent", 0|1): all layers of a decode step in one persistent launch
 #endif
 
-struct LlamaWs { bf16_t *x, *xn, *qkv, *q, *att, *act; unsigned* bar; void* sk; bf16_t* mega; size_t mega_stride; size_t bytes; };
+struct LlamaWs { bf16_t *x, *xn, *qkv, *q, *att, *act; unsigned* bar; void* sk; void* gsk; size_t gsk_bytes; bf16_t* mega; size_t mega_stride; size_t bytes; };
 LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     const size_t M = (size_t)B * T, h = w->hidden, F = w->ffn;
     const size_t Mp = (M + 15) / 16 * 16;            // fragment-major buffers hold whole 16-row tiles
@@ -1205,6 +1212,11 @@ LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     // serves prefills and decode steps alike (LlamaEngine's) must not have a prefill's activations land on the flag words - the sticky
     // error word among them is cleared by nobody but seedmi_llama_decode_status (zeroed once by the caller after allocation)
     void* const sk_area = c.take(SK2_WS_BYTES);
+    // ... and, behind it at a fixed offset too, the stream-K workspace of the prefill's MFMA GEMMs (seedmi_gemm_bf16_ws): flag words +
+    // one fp32 accumulator image per CU.  A prefill of 8 x 649 tokens at 14B width is 21 m-tiles: o_proj / down (N = 5120) are 420 tiles
+    // = 1.64 rounds of 256 CUs, i.e. 2 rounds data-parallel; cut into equal K ranges every workgroup ends together (bit-identical results)
+    t.gsk_bytes = seedmi_gemm_workspace_bytes();
+    t.gsk = c.take(t.gsk_bytes);
     t.x = (bf16_t*)c.take(M * h * 2);
     t.xn = (bf16_t*)c.take(Mp * h * 2);
     t.qkv = (bf16_t*)c.take(M * 3 * h * 2);
@@ -1283,14 +1295,22 @@ int decode_layers_launch(const seedmi_llama_weights_t* w, const LlamaWs& t, int 
 
 // dispatch: decode-sized M goes to the weight-streaming kernel, everything else to the 128x128 MFMA GEMM
 int linear(int M, int N, int K, const void* A, int lda, const void* W, const void* Wp, const void* R, int ldr, int epi,
-           void* C, int ldc, void* s, int a_packed = 0, int c_packed = 0, void* sk_ws = nullptr) {
+           void* C, int ldc, void* s, int a_packed = 0, int c_packed = 0, void* sk_ws = nullptr, void* gemm_ws = nullptr,
+           size_t gemm_ws_bytes = 0) {
     if (M <= 64 && (K % 128) == 0) {
         if (Wp && a_packed && sk_ws)
             return seedmi_gemm_skinny_norm_ws_bf16(M, N, K, A, 1, Wp, 0.f, R, ldr, epi, C, ldc, c_packed, nullptr, sk_ws, SK2_WS_BYTES, s);
         if (Wp) return seedmi_gemm_skinny_packed_bf16(M, N, K, A, lda, Wp, R, ldr, epi, C, ldc, a_packed, c_packed, s);
         return seedmi_gemm_skinny_bf16(M, N, K, A, lda, W, K, R, ldr, epi, C, ldc, s);
     }
-    return seedmi_gemm_bf16(M, N, K, A, lda, W, K, nullptr, R, ldr, epi, C, ldc, 0, 0, s);
+    // (with a workspace the persistent 256x256 kernel balances a partial last round of tiles by stream-K; NULL = data-parallel walk)
+    if (gemm_ws && g_prefill_streamk.load(std::memory_order_relaxed) == 2) {
+        const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+        const int n_cu = seedmi_device_cus(seedmi_current_device());
+        const long long last = tiles % n_cu;
+        if (!(tiles < 3LL * n_cu && last != 0 && 4 * last < 3LL * n_cu)) gemm_ws = nullptr;
+    }
+    return seedmi_gemm_bf16_ws(M, N, K, A, lda, W, K, nullptr, R, ldr, epi, C, ldc, 0, 0, gemm_ws, gemm_ws_bytes, s);
 }
 
 // ------------------------------------------------------------------------------------------------ prefill attention, tiled
@@ -1500,6 +1520,7 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_splitk") && (value >= 0 && value <= 3)) { g_skinny_sk = value; return SEEDMI_OK; }
+    if (!strcmp(key, "prefill_streamk") && (value >= 0 && value <= 2)) { g_prefill_streamk = value; return SEEDMI_OK; }
 #ifdef SEEDMI_DEVTOOLS
     if (!strcmp(key, "skinny_splitk") && value == 4) { g_skinny_sk = value; return SEEDMI_OK; }
 #endif
@@ -1857,6 +1878,13 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
         }
         return SEEDMI_OK;
     };
+    // stream-K tail of the MFMA GEMMs (prefill, M > 64): its flag words are cleared once per call, so the workspace's history (another
+    // shape's activations may have lived there before this area moved to the front) never matters
+    void* const gsk = (M > 64 && g_prefill_streamk.load(std::memory_order_relaxed)) ? t.gsk : nullptr;
+    if (gsk && hipMemsetAsync(gsk, 0, 4096, (hipStream_t)stream) != hipSuccess) {
+        seedmi_set_error("seedmi_llama_forward: clearing the stream-K flag words failed");
+        return SEEDMI_E_HIP;
+    }
     if (sk && !fused_first && hipMemsetAsync(sk, 0, (SK2_FLAG_WORDS - 1) * 4, (hipStream_t)stream) != hipSuccess) {     // (the kernels leave the
         seedmi_set_error("seedmi_llama_forward: clearing the split-K flag words failed");                       //  words zero: safety net)
         return SEEDMI_E_HIP;
@@ -1878,7 +1906,7 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
             else if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, M, h, stream));
             else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln1_w, w->rms_eps, t.xn, h, M, h, stream));
             CK(linear(M, 3 * h, h, t.xn, h, L.qkv_w, (pk || !w->norm_folded) ? L.qkv_wp : nullptr, nullptr, 0, EPI_NONE, t.qkv, 3 * h,
-                      stream, pk, 0, sk));
+                      stream, pk, 0, sk, gsk, t.gsk_bytes));
         }
         if (T == 1 && g_decode_fused) {
             // RoPE + cache append + attention in one launch (bit-identical to the two-kernel form below)
@@ -1897,13 +1925,13 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
                                                sk, skb, stream));
             CK(seedmi_gemm_skinny_norm_ws_bf16(M, h, F, t.act, 1, L.down_wp, 0.f, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, 0, t.xn, sk, skb, stream));
         } else {
-            CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0, sk));
+            CK(linear(M, h, h, t.att, h, L.o_w, L.o_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0, sk, gsk, t.gsk_bytes));
             if (pk && g_ablate_norm) {}
             else if (pk) CK(seedmi_rmsnorm_packed_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, M, h, stream));
             else CK(seedmi_rmsnorm_bf16(t.x, h, L.ln2_w, w->rms_eps, t.xn, h, M, h, stream));
             CK(linear(M, 2 * F, h, t.xn, h, L.gate_up_w, (pk || !w->norm_folded) ? L.gate_up_wp : nullptr, nullptr, 0, EPI_SWIGLU, t.act,
-                      F, stream, pk, pk, sk));
-            CK(linear(M, h, F, t.act, F, L.down_w, L.down_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0, sk));
+                      F, stream, pk, pk, sk, gsk, t.gsk_bytes));
+            CK(linear(M, h, F, t.act, F, L.down_w, L.down_wp, t.x, h, EPI_BIAS_RESIDUAL, t.x, h, stream, pk, 0, sk, gsk, t.gsk_bytes));
         }
     }
     const bool pk_head = (batch <= 64 && (h % 128) == 0 && w->lm_head_p);
@@ -1921,7 +1949,8 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
     } else {
         CK(seedmi_rmsnorm_bf16(t.x, h, w->norm_w, w->rms_eps, t.xn, h, M, h, stream));
         CK(tap_hidden(w->layers, t.xn));
-        CK(linear(M, w->vocab, h, t.xn, h, w->lm_head, w->norm_folded ? nullptr : w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream));
+        CK(linear(M, w->vocab, h, t.xn, h, w->lm_head, w->norm_folded ? nullptr : w->lm_head_p, nullptr, 0, EPI_NONE, logits, ldl, stream, 0, 0,
+                  nullptr, gsk, t.gsk_bytes));
     }
     return SEEDMI_OK;
 }

@@ -25,9 +25,29 @@ for r in range(4):                                    # 4 x (<img> 32 codes </im
 for _ in range(2):
     eng.reset(); eng.forward(ids, last_only=True)
 torch.cuda.synchronize()
+flops = B * T * 2.0 * cfg.linear_params() - (B * (T - 1)) * 2.0 * cfg.vocab * cfg.hidden + B * cfg.layers * 2.0 * T * T * cfg.hidden
+if os.environ.get("AB"):                              # interleaved A/B of option sets: AB="prefill_streamk=0|prefill_streamk=1"
+    import statistics
+    arms = os.environ["AB"].split("|")
+    ref, acc = None, {a: [] for a in arms}
+    for r in range(int(os.environ.get("ROUNDS", "5")) + 1):
+        for a in arms:
+            for kv in filter(None, a.split(",")):
+                k, v = kv.split("=")
+                L.check(L.load().seedmi_set_option(k.encode(), int(v)), kv)
+            eng.reset(); t = time.time(); lg = eng.forward(ids, last_only=True); torch.cuda.synchronize(); dt = time.time() - t
+            if r > 0:
+                acc[a].append(dt)
+            if ref is None:
+                ref = lg.clone()
+            elif not torch.equal(lg, ref):
+                print(f"!! {a}: logits differ from the first arm's", flush=True)
+    for a in arms:
+        m = statistics.median(acc[a])
+        print(f"{name} prefill B={B} T={T} [{a}]: median {m * 1e3:.2f} ms  {B * T / m:.0f} tok/s  {flops / m / 1e12:.0f} TFLOP/s ({flops / m / 2.5e15:.4f} of MFMA peak)", flush=True)
+    sys.exit(0)
 ts = []
 for _ in range(3):
     eng.reset(); t = time.time(); eng.forward(ids, last_only=True); torch.cuda.synchronize(); ts.append(time.time() - t)
 dt = sorted(ts)[1]
-flops = B * T * 2.0 * cfg.linear_params() - (B * (T - 1)) * 2.0 * cfg.vocab * cfg.hidden + B * cfg.layers * 2.0 * T * T * cfg.hidden
 print(f"{name} prefill B={B} T={T}: {dt * 1e3:.1f} ms  {B * T / dt:.0f} tok/s  {flops / dt / 1e12:.0f} TFLOP/s ({flops / dt / 2.5e15:.3f} of MFMA peak)", flush=True)
