@@ -37,6 +37,7 @@ struct VitAttnParams {
     int ldq, ldk, ldv, ldo;
     int n, heads, items;
     float scale;
+    int store_wait;               // 16-wave kernel: 1 = the K / Q wait tolerates the previous item's output stores (seedmi_set_option "attn_store_wait")
 #ifdef SEEDMI_DEVTOOLS
     unsigned long long* dbg;      // phase clock stamps of workgroup 0 (tools/attn_phase_times.py): [wave][item][6]
 #endif
@@ -58,6 +59,10 @@ SEEDMI_DEVINL void wait_vm(int leave) {                 // wave-uniform count of
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -392,12 +397,17 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
 #define V16STAMP(k_) do {} while (0)
 #endif
 
+    int stores_behind = 0;
     for (int it = 0;; ++it) {
         const int b = item / p.heads, h = item - b * p.heads;
         const int side_a = it & 15, side_b = (it + 6) & 15;           // waves that take row 256: scores + softmax / PV (different SIMDs)
         V16STAMP(0);
-        // ---- K(item), Q(item) landed everywhere (only this wave's V pieces may still be in flight)
-        wait_vm(my_pieces);
+        // ---- K(item), Q(item) landed everywhere (only this wave's V pieces may still be in flight).  vmcnt retires in order and counts
+        // stores: behind the K / Q requests of this item sit the previous item's output stores (issued at the end of its PV phase) and
+        // then the V pieces - counting only the V pieces would also wait for those stores to reach memory, a few hundred cycles after
+        // they were issued.  `stores_behind` is a lower bound of the store instructions this wave issued there (round 4; env
+        // SEEDMI_ATTN_STORE_WAIT=0 restores the old count for A/B).
+        wait_vm(my_pieces + stores_behind);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         V16STAMP(1);
@@ -651,6 +661,8 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
             }
             V16STAMP(6);
             store_o(o, wave, false);
+            // the tile's rows all exist (16 wave + li < 257): every store instruction of store_o has active lanes
+            stores_behind = p.store_wait ? (WIDE ? VHT / 2 : VHT) : 0;
         }
         V16STAMP(7);
         if (wave == side_b) {
@@ -705,6 +717,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
 // item - was written and measured: bit-identical rows, 162.0 us against 150.6 for mode 3 and 143.3 against 143.4 for mode 4
 // (profiles/r03_call9_attention_8wave.log): two waves per SIMD hide less latency than the halved LDS traffic buys.  Removed.)
 std::atomic<int> g_attn_vit{3};
+std::atomic<int> g_attn_store_wait{1};
 #undef V16STAMP
 #ifdef SEEDMI_DEVTOOLS
 unsigned long long* g_attn_dbg = nullptr;
@@ -719,6 +732,7 @@ extern "C" int seedmi_attn_vit_timing(void* buf) { g_attn_dbg = (unsigned long l
 
 int seedmi_attn_vit_enabled() { return g_attn_vit; }
 int seedmi_attn_vit_set(int v) { g_attn_vit = v; return SEEDMI_OK; }
+int seedmi_attn_vit_store_wait(int v) { g_attn_store_wait = v; return SEEDMI_OK; }
 
 // returns SEEDMI_OK after launching, or 1 if the shape is not handled by this kernel (caller falls back to attn_fullrow)
 int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
@@ -729,6 +743,7 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.n = nq; p.heads = heads; p.items = batch * heads; p.scale = scale;
+    p.store_wait = g_attn_store_wait.load(std::memory_order_relaxed);
 #ifdef SEEDMI_DEVTOOLS
     p.dbg = g_attn_dbg;
 #endif

@@ -862,6 +862,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr bool STATIC_SLOT = (SCHED & 1024) == 0 && EPI != EPI_BIAS_RESIDUAL;
     // bit 11 (two-phase K-tile): the fragment reads of a phase are waited for BEHIND the phase's barrier instead of in front of it
     constexpr bool LATEWAIT = (SCHED & 2048) != 0;
+    // (round 4, measured and removed - profiles/r04_call6_store_tolerant_waits.log: "store-tolerant" waits.  vmcnt retires in order and
+    // counts stores, so the two-phase loop's vmcnt(2) in phase b of a tile's FIRST K-tile also waits for the previous epilogue's 16 output
+    // stores, a fraction of a microsecond after they were issued.  Variant: the prologue requests both K-tiles of the ring in full (16
+    // requests, all ahead of the stores) and the two waits that concern only prologue requests allow a known lower bound of 16 younger
+    // stores to stay in flight, so that the first request behind the stores is not waited for before phase b of the SECOND K-tile.
+    // Bit-identical, no scratch - and 2.5-3.6 % SLOWER on all four ViT shapes, 125.5 vs 122.3 ms per tokenize pass: a request issued
+    // behind the stores queues behind them in the memory pipeline whatever the counter says, and the early wait was also what kept the
+    // store burst from overlapping the next tile's operand stream.)
     bool tile_ragged = false;
     static_assert(!TWOPH || (SCHED & 14) == 0, "the two-phase schedule has its own request placement");
     // (round 4: the branch form of the split inside the two-phase K-tile - phase a on every wave's own 64 x 64 block, phase b empty in a
