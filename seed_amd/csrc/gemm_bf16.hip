@@ -1008,8 +1008,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // prologue loads of a segment: its first K-tile (A and W) and, already in flight behind it, W of the second
     auto issue_prologue = [&](int kb, int ke) {
         if (FOLD_IN) {
-            // the tile's fold operands travel with its first K-tile, as its OLDEST LDS-DMA request (one 1 KiB piece per wave, waves
-            // 4-7 repeat pieces 0-3): complete, and published by the K loop's barriers, long before the epilogue reads them
+            // the tile's fold operands travel with its first K-tile, as its OLDEST LDS-DMA requests (1 KiB pieces dealt round-robin: wave w
+            // takes pieces w, w + 8, ...; with finished statistics that is one piece for waves 0-3 and none for waves 4-7): complete, and
+            // published by the K loop's barriers, long before the epilogue reads them
             // pieces: 0 column sums, 1 folded bias, then the statistics of the tile's 256 rows in 1 KiB halves (128 rows x 8 B): finished
             // (mean, rstd) pairs (2 pieces) or ln_planes partial planes (2 pieces each); wave w takes pieces w, w + 8
             const int ln = SCHED != 0 ? fresh_lane() : lane;

@@ -21,6 +21,7 @@ bias = torch.zeros(N, device="cuda").bfloat16()
 C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 L.check(lib.seedmi_set_option(b"gemm", v), "opt")
 fold = os.environ.get("FOLD", "1") == "1" and N % 64 == 0
+EPI = int(os.environ.get("EPI", str(L.EPI_BIAS)))       # 1 = BIAS, 2 = BIAS_GELU (the fc1 launch)
 if fold:
     stats = torch.zeros(M + (M & 1), 2, dtype=torch.float32, device="cuda")
     L.check(lib.seedmi_layernorm_stats_bf16(L.ptr(A), K, M, K, 1e-6, L.ptr(stats), L.stream_ptr()), "stats")
@@ -28,9 +29,9 @@ if fold:
     ext = L.GemmExt(L.ptr(stats), L.ptr(cs), L.ptr(b32), None, 0)
 for _ in range(iters):
     if fold:
-        L.check(lib.seedmi_gemm_bf16_ext(M, N, K, L.ptr(A), K, L.ptr(W), K, None, None, 0, L.EPI_BIAS, L.ptr(C), N, 0, 0, ctypes.byref(ext),
+        L.check(lib.seedmi_gemm_bf16_ext(M, N, K, L.ptr(A), K, L.ptr(W), K, None, None, 0, EPI, L.ptr(C), N, 0, 0, ctypes.byref(ext),
                                          None, 0, L.stream_ptr()), "gemm ext")
     else:
-        L.check(lib.seedmi_gemm_bf16(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, L.EPI_BIAS, L.ptr(C), N, 0, 0,
+        L.check(lib.seedmi_gemm_bf16(M, N, K, L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, 0, EPI, L.ptr(C), N, 0, 0,
                                      L.stream_ptr()), "gemm")
 torch.cuda.synchronize()
