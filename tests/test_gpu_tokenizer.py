@@ -254,10 +254,14 @@ def test_full_size_batch256_against_live_reference_modules():
     ref = ref_shims.load_reference_modules()
     mods = ref_shims.build_reference_tokenizer_modules(ref, cfg)
     make_golden.load_tokenizer_weights(mods, sd)
+    threads0 = torch.get_num_threads()
     torch.set_num_threads(min(os.cpu_count() or 1, 16))              # (the bench line's thread sweep on the GPU box: 16 threads are fastest for these modules)
     t0 = time.time()
     sub = img[rows].float()
-    _, taps_ref = ref_shims.reference_get_codebook_indices(mods, sd["query_tokens"].clone(), sub)
+    try:
+        _, taps_ref = ref_shims.reference_get_codebook_indices(mods, sd["query_tokens"].clone(), sub)
+    finally:
+        torch.set_num_threads(threads0)
     cb = calibrate_codebook(taps_ref["z"], cfg.n_embed, seed=7)
     mods.quantize.embedding.weight.data.copy_(cb)
     ids_ref = mods.quantize(taps_ref["z"])[2].reshape(len(rows), -1)                         # VectorQuantizer2.forward on the same z
