@@ -130,7 +130,7 @@ def qkv_gemm_roofline(batch):
             traffic = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
             traffic_src = "profiles/" + name + " (rocprofv3 --pmc passes of this launch, tools/pmc_qkv.sh; NOT measured in this run)"
             break
-    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS, LayerNorm fold, schedule 81 (two-phase K-tile)>, persistent (ViT norm1 + QKV: M=%d K=%d N=%d)" % (M, K, N),
+    return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS, LayerNorm fold, schedule 8273 (two-phase K-tile, position-free body)>, persistent (ViT norm1 + QKV: M=%d K=%d N=%d)" % (M, K, N),
             "launch": "BASELINE-defined M = batch * 257 = %d launch (the tokenize path issues 2 x M = %d on two streams: in_path_launch)" % (M, Mh),
             "in_path_launch": {"M": Mh, "avg_launch_ms": round(half_ms, 4), "achieved": round(2.0 * Mh * N * K / (half_ms * 1e-3) / 1e12, 1),
                                "note": "isolated on one stream; inside seedmi_tokenize two such launches overlap"},

@@ -57,7 +57,7 @@ int seedmi_check_device(void);
  * tail for the tokenizer's big GEMMs, default 0), "tokenize_lnfold" (0|1: LayerNorm folded into qkv / fc1 when the weights carry
  * the folded copies, default 1), "tokenize_split_rounds" (0|1: a big GEMM whose 256x256 tiles overshoot a whole number of rounds by
  * a few m-tiles runs those rows as a second, 128x128-tiled call; pays on one stream only, default 0), "tokenize_vq_head" (0|1: the head's last Linear fused into the VQ argmin kernel, default 1),
- * "gemm_sched" (schedule of the 256x256 kernel for the ViT epilogues: -1 = default (81: two-phase K-tile), 31 = the four-phase K-tile with counted waits and split requests, 0 = the round-2 schedule; bit-identical results),
+ * "gemm_sched" (schedule of the 256x256 kernel for the ViT epilogues: -1 = default (8273: two-phase K-tile with the position-free body), 81 = the same with position-guarded requests (the round-3 default), 31 = the four-phase K-tile with counted waits and split requests, 0 = the round-2 schedule; bit-identical results),
  * "tokenize_tile_stats" (0|1: LayerNorm statistics by 256-column tile, finalized inside the consuming GEMM instead of by
  * seedmi_layernorm_stats_finalize launches; large batches only),
  * "skinny_waves" / "skinny_rows"

@@ -53,7 +53,7 @@ std::atomic<int> g_gemm_variant{0};  // "gemm": 0 = auto, 128 / 256 = force a ke
 // "gemm_sched": schedule variant of the 256x256 kernel (bits: see gemm256_kernel) for the three ViT epilogues.  31 = every measured gain of
 // round 3 (epilogue-side wait, W pre-read, two LDS-DMA requests per phase with counted waits, early residual requests): bit-identical to
 // schedule 0, +3..5 % per GEMM, +3.4 % end to end (profiles/r03_gemm_sched_ab_call*.json).  0 = the round-2 schedule.
-constexpr int GEMM_SCHED_DEFAULT = 81;           // two-phase K-tile + counted waits across tile boundaries + early residual rows (see gemm256_kernel)
+constexpr int GEMM_SCHED_DEFAULT = 8273;         // two-phase K-tile + counted waits across tile boundaries + early residual rows + position-free body (see gemm256_kernel)
 std::atomic<int> g_gemm_sched{GEMM_SCHED_DEFAULT};
 #ifdef SEEDMI_DEVTOOLS
 unsigned long long* g_gemm_dbg = nullptr;   // seedmi_gemm_phase_timing: device buffer for the phase clock stamps
@@ -870,6 +870,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // Bit-identical, no scratch - and 2.5-3.6 % SLOWER on all four ViT shapes, 125.5 vs 122.3 ms per tokenize pass: a request issued
     // behind the stores queues behind them in the memory pipeline whatever the counter says, and the early wait was also what kept the
     // store burst from overlapping the next tile's operand stream.)
+    // bit 13 (two-phase K-tile, round 4): UNIFORM loop body - no K-tile looks at its position inside the segment.  Calls 9 / 10 of round 4
+    // showed what wave-uniform branches cost this loop (the seam-request variant lost 5-7 % with its branches compiled in and never taken), and
+    // peeling first / last K-tiles into bodies of their own makes hipcc spill 300+ B per lane.  Here every K-tile issues its eight requests
+    // and waits with the steady-state counts; the requests that would reach beyond the segment re-fetch its LAST K-tile (L2-hot) into ring slots
+    // nobody reads any more - 14 wasted requests per tile - and the next segment's prologue, issued by the same waves behind them, lands last.
+    // Bit-identical on all four ViT shapes (race screen included), no scratch; measured on two boxes (profiles/r04_call11_/r04_call12_
+    // uniform_ktile_body.log): QKV +0.2..0.3 %, proj +0.2..0.4 %, fc1 +0.2..0.4 %, fc2 +1.0..1.4 %, the tokenize pass +0.5 % both times
+    // (122.09 vs 122.73 ms, 120.11 vs 120.73 ms).  Small, and the only schedule change of round 4 that did not lose: the default (8273 = 81 + 8192).
+    constexpr bool UNIFORM = TWOPH && (SCHED & 8192) != 0;
     bool tile_ragged = false;
     static_assert(!TWOPH || (SCHED & 14) == 0, "the two-phase schedule has its own request placement");
     // (round 4: the branch form of the split inside the two-phase K-tile - phase a on every wave's own 64 x 64 block, phase b empty in a
@@ -978,9 +987,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) dmaA(offA[h][j], k0, base + h * HALF_BYTES + (TWOPH ? j * 8192 : j * 1024));
     };
-    auto stageA_rows = [&](int kt, int j) {  // TWOPH: this wave's mh0 (j = 0) or mh1 (j = 1) piece of both A half-tiles
+    // (kidx >= 0: ring slot of K-tile kt, data of K-tile kidx)
+    auto stageA_rows = [&](int kt, int j, int kidx = -1) {  // TWOPH: this wave's mh0 (j = 0) or mh1 (j = 1) piece of both A half-tiles
         char* base = smem + (kt & 1) * RING_SLOT + wave * 1024 + j * 8192;
-        const int k0 = kt * BK;
+        const int k0 = (kidx < 0 ? kt : kidx) * BK;
 #pragma unroll
         for (int h = 0; h < 2; ++h) dmaA(offA[h][j], k0, base + h * HALF_BYTES);
     };
@@ -990,9 +1000,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) dmaA(offA[h][j], k0, base + h * HALF_BYTES + j * 1024);
     };
-    auto stageW = [&](int kt) {
+    auto stageW = [&](int kt, int kidx = -1) {
         char* base = smem + RING_W + (kt & 1) * RING_SLOT + wave * 2048;
-        const int k0 = kt * BK;
+        const int k0 = (kidx < 0 ? kt : kidx) * BK;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1292,7 +1302,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // ================= phase a: rows mh0 x (nh0, nh1) =================
         // A-mh1(kt), requested in phase a of kt-1, is read in phase b: everything but the six requests of phase b of kt-1 must have landed
         // (the segment's first K-tile came with the prologue and was waited for at the tile's opening)
-        if (kt > kb) {
+        if (UNIFORM) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // (first K-tile: the opening wait left at most six in flight already)
+        } else if (kt > kb) {
             if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1302,7 +1314,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         for (int t = 0; t < 2; ++t) { fw1[t] = *(const bf16x8*)(pw0 + (2 + t) * 512); fw1[2 + t] = *(const bf16x8*)(pw1 + (2 + t) * 512); }
 #pragma unroll
         for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
-        if (kt + 1 < ke) stageA_rows(kt + 1, 1);        // mh1 rows of the other parity: last read in phase b of kt-1, retired before its barrier
+        // mh1 rows of the other parity: last read in phase b of kt-1, retired before its barrier
+        if (UNIFORM) stageA_rows(kt + 1, 1, min(kt + 1, ke - 1));
+        else if (kt + 1 < ke) stageA_rows(kt + 1, 1);
         if (!LATEWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
@@ -1323,10 +1337,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         // ================= phase b: rows mh1 x the same W fragments =================
         // W(kt+1) and A-mh0(kt+1) (phase b of kt-1, or the prologue) are read in phase a of kt+1: only this K-tile's two requests stay in flight
-        if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (UNIFORM || kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
-        if (kt + 2 < ke) {                              // this parity's W and mh0 rows were last read in phase a, retired before its barrier
+        if (UNIFORM) {                                  // this parity's W and mh0 rows were last read in phase a, retired before its barrier
+            stageW(kt + 2, min(kt + 2, ke - 1));
+            stageA_rows(kt + 2, 0, min(kt + 2, ke - 1));
+        } else if (kt + 2 < ke) {
             stageW(kt + 2);
             stageA_rows(kt + 2, 0);
         }
@@ -1454,20 +1471,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
     } else if ((live || ragged) && TWOPH) {
         // (a pair-unrolled form with compile-time ring slots - as in the four-phase loop - costs 64 B of scratch here: run-time slots)
+        // (measured and removed, round 4 call 12: the same loop pair-unrolled with compile-time ring slots - segments start on even
+        //  K-tiles - compiles with 12-52 B of scratch and runs proj -4.3 %, fc2 -4.6 %, QKV/fc1 equal, the pass -1.9 %:
+        //  profiles/r04_call12_uniform_ktile_body.log.  The four v_add per K-tile of the run-time slots are cheaper than two bodies.)
         for (int kt = kb; kt < ke; ++kt) ktile2(slot_dyn(), kt, kb, ke);
     } else if (!live && TWOPH) {
         // same requests, waits and barriers as ktile2, no fragment reads, no MFMA
         for (int kt = kb; kt < ke; ++kt) {
-            if (kt > kb) {
+            if (UNIFORM) {
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else if (kt > kb) {
                 if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (kt + 1 < ke) stageA_rows(kt + 1, 1);
+            if (UNIFORM) stageA_rows(kt + 1, 1, min(kt + 1, ke - 1));
+            else if (kt + 1 < ke) stageA_rows(kt + 1, 1);
             SEEDMI_SCHED_FENCE();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
-            if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            if (kt + 2 < ke) {
+            if (UNIFORM || kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (UNIFORM) {
+                stageW(kt + 2, min(kt + 2, ke - 1));
+                stageA_rows(kt + 2, 0, min(kt + 2, ke - 1));
+            } else if (kt + 2 < ke) {
                 stageW(kt + 2);
                 stageA_rows(kt + 2, 0);
             }
@@ -1675,7 +1701,8 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
 #ifdef SEEDMI_SCHED_ONLY                               // (register-pressure experiments: one variant, short compile)
             case SEEDMI_SCHED_ONLY: return launch_gemm256_sched<EPI, LNF, SEEDMI_SCHED_ONLY>(p, stream, sk_ws, sk_ws_bytes);
 #else
-            case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);      // two-phase K-tile: the default
+            case 8273: return launch_gemm256_sched<EPI, LNF, 8273>(p, stream, sk_ws, sk_ws_bytes);  // two-phase K-tile with the position-free body: the default
+            case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);      // two-phase K-tile, requests guarded by position (the default of round 3)
             case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);      // four-phase K-tile (the default before the buffer-form requests)
 #ifdef SEEDMI_DEVTOOLS                                 // measured steps (tools/gemm_sched_ab.py)
             case 7: return launch_gemm256_sched<EPI, LNF, 7>(p, stream, sk_ws, sk_ws_bytes);
@@ -1697,6 +1724,7 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
     // the other epilogues (plain, SwiGLU, tanh, ReLU: LLaMA prefill, the head MLPs) take the two-phase K-tile too - one variant each
     if constexpr (!LNF && (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_BIAS_TANH || EPI == EPI_RELU)) {
 #ifndef SEEDMI_SCHED_ONLY
+        if (g_gemm_sched.load() == 8273) return launch_gemm256_sched<EPI, LNF, 8257>(p, stream, sk_ws, sk_ws_bytes);
         if (g_gemm_sched.load() == 81) return launch_gemm256_sched<EPI, LNF, 65>(p, stream, sk_ws, sk_ws_bytes);
 #endif
     }
@@ -1761,7 +1789,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 4095) {      // (-1 = the default; values without a compiled variant run schedule 0)
+    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 16383) {      // (-1 = the default; values without a compiled variant run schedule 0)
         if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
         return SEEDMI_OK;

@@ -69,10 +69,11 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[128, 256, (256, 0)], ids=["gemm128", "gemm256", "gemm256_sched0"])
+@pytest.fixture(params=[128, 256, (256, 0), (256, 81)], ids=["gemm128", "gemm256", "gemm256_sched0", "gemm256_sched81"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (128x128 two-barrier and 256x256 staggered deep pipeline), the 256x256 kernel
-    under its default schedule (gemm_sched 31, round 3) and under the round-2 schedule (0) that stays selectable."""
+    under its default schedule (gemm_sched 8273: two-phase K-tile, position-free body, round 4), under the round-2 schedule (0) and
+    under the round-3 default (81, position-guarded requests) that both stay selectable."""
     variant, sched = request.param if isinstance(request.param, tuple) else (request.param, -1)
     L.check(lib.seedmi_set_option(b"gemm", variant), "set_option")
     L.check(lib.seedmi_set_option(b"gemm_sched", sched), "set_option")
@@ -307,7 +308,7 @@ def test_gemm_residual_emits_layernorm_statistics(lib, gemm_variant):
     assert torch.allclose(stats[:, 1].cpu().double(), torch.rsqrt(y.var(1, unbiased=False) + 1e-6), rtol=1e-4)
 
 
-@pytest.mark.parametrize("sched", [0, 31], ids=["sched0", "sched31"])
+@pytest.mark.parametrize("sched", [0, 31, -1], ids=["sched0", "sched31", "default"])
 def test_layernorm_statistics_by_tile_with_outlier_channels(lib, sched):
     """The LayerNorm fold chain as the tokenizer runs it at large batch (eva_vit.py:199-202): proj / fc2 (BIAS_RESIDUAL) emit one
     (sum, sum of squares) pair per row and 256-column TILE, the consuming qkv / fc1 GEMM finalizes its tiles' rows itself - no
