@@ -63,9 +63,12 @@ int seedmi_check_device(void);
  * "skinny_waves" / "skinny_rows"
  * (decode GEMM; "skinny_nt" = 0, temporal weight loads, exists in the devtools build only), "skinny_splitk" (which kernel seedmi_gemm_skinny_norm_ws_bf16 runs: 0 = the one-tile-per-workgroup kernel | 1 = the split-K kernel, uncut where the shape divides into whole tiles per workgroup: the default | 2 = the split-K kernel, always cut | 3 = the split-K kernel only where the one-tile form would leave its last round of workgroups under 95 % full), "prefill_streamk" (0|1|2: stream-K tail for the prefill's MFMA GEMMs through the llama workspace - off (default, measured faster) | every GEMM | only short GEMMs with a badly filled last round; same bits either way), "decode_fused" (0|1 RoPE + append inside decode attention), "decode_attn_early" (fused decode attention: 0 = cached rows requested after the rotation | 1 = first batch of key rows requested ahead of it: the default | 2 = key and value rows; same bits), "prefill_tiled" (0|1), "attn_store_wait" (0|1: the sixteen-wave ViT kernel's wait for the next item's K / Q leaves the previous item's output stores in flight, default 1; same bits), "attn_trv" / "attn_vit"
  * (attention kernel selection; attn_vit, for the ViT's 257-token / head-dim-88 shape: 0 = generic full-row kernel | 1 = twelve-wave ViT kernel |
- * 2 = sixteen-wave ViT kernel | 3 = sixteen-wave kernel with 16-byte output stores: the DEFAULT, same bits as 1 and 2 |
+ * 2 = sixteen-wave ViT kernel | 3 = sixteen-wave kernel with 16-byte output stores, same bits as 1 and 2 |
  * 4 = sixteen-wave kernel with "flash" normalisation (P rounded to half BEFORE the division by the row sum): faster, but NOT
- * bit-compatible with 0-3 - it moves a rounding point of eva_vit.py:139-156 by about 0.8 bf16 ulp rms, token ids form their own equality group).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
+ * bit-compatible with 0-3 - it moves a rounding point of eva_vit.py:139-156 by about 0.8 bf16 ulp rms, token ids form their own equality group |
+ * 5 = kernel 3 with the two halves of the workgroup one phase apart (softmax of one half next to the MFMA / LDS phases of the other),
+ * wave priorities per phase and - for >= 64 images on a full launch - all heads of an image on one XCD ("attn_xcd", 0|1, default 1):
+ * the DEFAULT since round 4, bit-identical to 3 | 6 = kernel 4 in that form, bit-identical to 4 | 7 = 5 without the priorities (A/B)).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
 int seedmi_set_option(const char* key, int value);
 

@@ -229,8 +229,9 @@ int launch_attn(const AttnParams& p, int batch, hipStream_t stream) {
 
 int seedmi_attn_set_option(const char* key, int value) {
     if (!strcmp(key, "attn_trv") && (value == 0 || value == 1)) { g_attn_trv = value; return SEEDMI_OK; }
-    if (!strcmp(key, "attn_vit") && value >= 0 && value <= 4) return seedmi_attn_vit_set(value);
+    if (!strcmp(key, "attn_vit") && value >= 0 && value <= 7) return seedmi_attn_vit_set(value);
     if (!strcmp(key, "attn_store_wait") && (value == 0 || value == 1)) return seedmi_attn_vit_store_wait(value);
+    if (!strcmp(key, "attn_xcd") && (value == 0 || value == 1)) return seedmi_attn_vit_xcd(value);
     return SEEDMI_E_SHAPE;
 }
 

@@ -494,24 +494,28 @@ def ref_attention(q, k, v, heads, scale, causal, round_s=True):
     return r(p @ vh).transpose(1, 2).reshape(B, nq, C)
 
 
-DEFAULT_ATTN_VIT = 3          # the library's default ViT attention kernel (seed_amd/csrc/attn_vit.hip: g_attn_vit)
+DEFAULT_ATTN_VIT = 5          # the library's default ViT attention kernel (seed_amd/csrc/attn_vit.hip: g_attn_vit)
 
 
 @pytest.mark.parametrize("B,H,hd,nq,nk,causal", [
     (3, 16, 88, 257, 257, False),     # ViT
     (40, 16, 88, 257, 257, False),    # ViT, more items than CUs (persistent kernel walks > 1 item per workgroup)
+    (72, 16, 88, 257, 257, False),    # ViT, >= 64 images: the staggered kernel's XCD-aware item walk (9 images per XCD: 4.5 rounds of its 32 workgroups)
     (2, 3, 88, 100, 100, False),
     (2, 4, 88, 17, 17, False),        # small ViT (NKP=32 path)
     (5, 12, 64, 32, 32, True),        # Q-Former causal self-attention
     (4, 12, 64, 32, 257, False),      # Q-Former cross-attention
     (2, 2, 64, 17, 17, False),
 ])
-@pytest.mark.parametrize("trv", [5, 4, 3, 2, 1, 0], ids=["vit_16wave_flash", "vit_16wave_wide", "vit_16wave", "vit_pipeline", "tr_read", "vt_image"])
+@pytest.mark.parametrize("trv", [7, 6, 5, 4, 3, 2, 1, 0], ids=["vit_16wave_staggered_flash", "vit_16wave_staggered", "vit_16wave_flash", "vit_16wave_wide", "vit_16wave",
+                                                            "vit_pipeline", "tr_read", "vt_image"])
 def test_attention_fullrow(lib, B, H, hd, nq, nk, causal, trv):
     if trv >= 3 and not (nq == nk == 257 and hd == 88 and not causal):
         pytest.skip("the 16-wave kernel serves the 257-token ViT shape only (other shapes take the same kernels as vit_pipeline)")
+    if B == 72 and trv not in (6, 7, 4):
+        pytest.skip("the 72-image case exists for the staggered kernel's XCD-aware walk (and one lock-step run beside it)")
     default_vit = DEFAULT_ATTN_VIT
-    L.check(lib.seedmi_set_option(b"attn_vit", {5: 4, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "set_option")
+    L.check(lib.seedmi_set_option(b"attn_vit", {7: 6, 6: 5, 5: 4, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "set_option")
     L.check(lib.seedmi_set_option(b"attn_trv", min(trv, 1)), "set_option")
     gen = torch.Generator().manual_seed(B * 100 + nk)
     C = H * hd
@@ -535,7 +539,15 @@ def test_attention_fullrow(lib, B, H, hd, nq, nk, causal, trv):
     vf = V[:, :C].float().reshape(B, nk, C)
     want = ref_attention(qf, kf, vf, H, scale, causal)
     lib.seedmi_set_option(b"attn_trv", 1)
-    if trv in (3, 4):
+    if trv in (6, 7):
+        # the staggered form does every wave's work exactly as the lock-step 16-wave kernel does: bit-identical, row 256 included
+        lib.seedmi_set_option(b"attn_vit", 3 if trv == 6 else 4)
+        ref16 = torch.full_like(out, float("nan"))
+        L.check(lib.seedmi_attention_bf16(L.ptr(Q), ldq, L.ptr(K), ld, L.ptr(V), ld, L.ptr(ref16), C, B, H, hd, nq, nk, scale, 0, 1,
+                                          L.stream_ptr()), "attention")
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), ref16.view(torch.int16)), "the staggered 16-wave kernel differs from the lock-step one"
+    if trv in (3, 4, 6):
         # same arithmetic and rounding points as the 12-wave kernel (row 256 goes through a differently shaped reduction: compared to 1 ulp)
         lib.seedmi_set_option(b"attn_vit", 1)
         ref12 = torch.zeros_like(out)

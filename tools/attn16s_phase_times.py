@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Where an item's time goes in the 16-wave ViT attention kernel (devtools build: SEEDMI_LIB_PATH=seed_amd/libseedmi_dev.so).
-Every wave of workgroup 0 stamps s_memtime into SGPRs at nine points of its first 8 items and stores them at the item's end:
-  0 item start | 1 K, Q landed (barrier) | 2 QK^T done | 3 softmax done | 4 side job A done | 5 V landed (barrier) | 6 PV done | 7 stored |
-  8 side job B done.   MODE=2|3|4 selects attn_vit (plain / 16-byte stores / + normalisation behind PV)."""
+"""Slot times of the staggered 16-wave ViT attention kernel (attn_vit = 5 / 6; devtools build: SEEDMI_LIB_PATH=seed_amd/libseedmi_dev.so).
+Every wave of workgroup 0 stamps s_memtime at seven points of its first 8 items:
+  0 slot start | 1 QK^T done | 2 barrier passed | 3 softmax (+ side scores) done | 4 barrier passed | 5 PV (+ side PV) done | 6 barrier passed
+Group A = waves 0..7, group B = waves 8..15 (one slot behind)."""
 import ctypes
 import os
 import sys
@@ -28,8 +28,8 @@ def run():
                                       hd ** -0.5, 0, 1, L.stream_ptr()), "attention")
 
 
-names = ["wait K", "QK^T", "softmax", "side A", "wait V", "PV", "store", "side B"]
-for mode in [int(v) for v in os.environ.get("MODES", "3,4").split(",")]:
+names = ["QK^T", "wait", "softmax", "wait", "PV", "wait"]
+for mode in [int(v) for v in os.environ.get("MODES", "5,6").split(",")]:
     L.check(lib.seedmi_set_option(b"attn_vit", mode), "attn_vit")
     for _ in range(20):
         run()
@@ -47,12 +47,17 @@ for mode in [int(v) for v in os.environ.get("MODES", "3,4").split(",")]:
         run()
     torch.cuda.synchronize()
     L.check(lib.seedmi_attn_vit_timing(None), "timing off")
-    t = buf.cpu().view(16, 8, 9).double()
-    for w in (0, 1, 5, 10, 15):
-        d = t[w, 1:7, 1:] - t[w, 1:7, :-1]                     # items 1..6
-        per = (t[w, 2:8, 0] - t[w, 1:7, 0]).mean().item()
+    t = buf.cpu().view(16, 8, 9).double()[:, :, :7]
+    for w in (0, 1, 4, 7, 8, 9, 12, 15):
+        d = t[w, 1:6, 1:] - t[w, 1:6, :-1]                     # items 1..5
+        per = (t[w, 2:7, 0] - t[w, 1:6, 0]).mean().item()
         print("  wave %2d: " % w + "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names, d.mean(0).tolist())) + "   | item period %.0f cycles" % per)
-    allw = (t[:, 1:7, 1:] - t[:, 1:7, :-1]).mean(1)             # [16, 8]
-    print("  mean over waves: " + "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names, allw.mean(0).tolist())),
-          "| max over waves: " + "  ".join("%.0f" % v for v in allw.max(0).values.tolist()))
+    for name, ws in (("group A", slice(0, 8)), ("group B", slice(8, 16))):
+        allw = (t[ws, 1:6, 1:] - t[ws, 1:6, :-1]).mean(1)
+        print("  %s mean: " % name + "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names, allw.mean(0).tolist())),
+              "| max: " + "  ".join("%.0f" % v for v in allw.max(0).values.tolist()))
+    # slot lengths seen by wave 0 (barrier to barrier): slot 3k = t2 - t0, 3k+1 = t4 - t2, 3k+2 = t6 - t4
+    w0 = t[0, 1:6]
+    print("  slots (wave 0): 3k %.0f  3k+1 %.0f  3k+2 %.0f" % ((w0[:, 2] - w0[:, 0]).mean().item(), (w0[:, 4] - w0[:, 2]).mean().item(),
+                                                               (w0[:, 6] - w0[:, 4]).mean().item()))
 lib.seedmi_set_option(b"attn_vit", 5)

@@ -15,8 +15,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B * N, 3 * C, device="cuda", generator=g).bfloat16()
 out = torch.empty(B * N, C, device="cuda", dtype=torch.bfloat16)
 flops = 4.0 * B * H * N * N * hd
-for trv in (5, 4, 3, 2, 1):                               # 5 / 4 / 3 = 16-wave ViT kernel (flash + wide stores / wide stores / plain), 2 = 12-wave, 1 = attn_fullrow
-    L.check(lib.seedmi_set_option(b"attn_vit", {5: 4, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "opt")
+for trv in (7, 6, 5, 4, 3, 2, 1):                         # 7 / 6 = staggered 16-wave kernel (flash / default), 5 / 4 / 3 = lock-step 16-wave kernel (flash + wide stores / wide stores / plain), 2 = 12-wave, 1 = attn_fullrow
+    L.check(lib.seedmi_set_option(b"attn_vit", {7: 6, 6: 5, 5: 4, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "opt")
     L.check(lib.seedmi_set_option(b"attn_trv", min(trv, 1)), "opt")
     ts = []
     for i in range(12):
@@ -31,4 +31,4 @@ for trv in (5, 4, 3, 2, 1):                               # 5 / 4 / 3 = 16-wave 
     med = sorted(ts)[len(ts) // 2]
     print(f"trv={trv}: {med * 1e3:.1f} us  {flops / med / 1e9:.1f} TFLOP/s", flush=True)
 lib.seedmi_set_option(b"attn_trv", 1)
-lib.seedmi_set_option(b"attn_vit", 3)
+lib.seedmi_set_option(b"attn_vit", 5)

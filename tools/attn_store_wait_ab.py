@@ -48,5 +48,5 @@ for r in range(7):
 for a in arms:
     med = statistics.median(times[a])
     print(f"attn_vit={a[0]} attn_store_wait={a[1]}: {med * 1e3:.1f} us  {flops / med / 1e9:.1f} TFLOP/s", flush=True)
-lib.seedmi_set_option(b"attn_vit", 3)
+lib.seedmi_set_option(b"attn_vit", 5)
 lib.seedmi_set_option(b"attn_store_wait", 1)
