@@ -731,7 +731,8 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
 //   the stagger alone                                             129.7  [138.5]
 //   + cheaper staging addresses, max3 chain                       127.2  [134.2]   (the VALU saved - a quarter of a wave's instructions - bought 1 %)
 //   + XCD-aware item walk (all heads of an image on one XCD)      119.7  [133.3]   (plain walk on the same box: 128.8)
-//   + wave priorities softmax > PV > QK^T                         114.6  [133.6]   = -14 %; the tokenize pass 120.80 vs 121.64 ms (+0.7 %)
+//   + wave priorities softmax > PV > QK^T                         114.6  [133.6]   the tokenize pass 120.80 vs 121.64 ms (+0.7 %)
+//   + the last key tile's three non-existent keys skipped         112.7  [132.6]   = -15 %
 // What did NOT help: K fragments two key tiles ahead; fencing the fragment requests in front of the MFMAs (hipcc sinks them to 2-3 MFMAs
 // of distance: restoring the written order is 3 % slower); dealing the side row's PV over six waves (kept: no slower, and no wave runs a
 // second PV pass); the normalisation behind PV (attn_vit = 6: 118.6 - slower than the exact form now).  Slot stamps (devtools build):
@@ -748,6 +749,8 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
     // against B's 6.1 k, softmax 4.2 k against 8.4 k).  Measured at B = 128 (profiles/r04_call20_attention_priorities.log), {QK^T, softmax,
     // PV} = none 118.4 us | {3,2,1} 116.9 | {2,3,1} 116.7 | {3,1,2} 119.9 | {1,3,2} 114.3 | {1,2,3} 117.7.
     constexpr bool PRS = (MODE & 4) == 0;
+    // (measured and removed, profiles/r04_call24_attention_last_tile.log: the side row's scores in group A's QK^T slot - the shortest phase of
+    // the three - with two side rows in LDS taken in turn: 121.2 us against 112.7)
     constexpr int PR_QK = 1, PR_SM = 3, PR_PV = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ksm = (bf16_t*)smem;
@@ -890,12 +893,16 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
         float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int kt = 0; kt < VNT; ++kt) {
-            const uint32_t w0 = pack2bf(s[kt][0], s[kt][1]), w1 = pack2bf(s[kt][2], s[kt][3]);
-            float v0 = lo_bf(w0), v1 = hi_bf(w0), v2 = lo_bf(w1), v3 = hi_bf(w1);
-            if (kt == VNT - 1) {                             // keys 256 .. 271: only key 256 (g == 0, r == 0) exists
-                v0 = (g == 0) ? v0 : -INFINITY;
-                v1 = v2 = v3 = -INFINITY;
+            if (kt == VNT - 1) {
+                // keys 256 .. 271: only key 256 (g == 0, r == 0) exists.  The three other registers of this tile are never touched again:
+                // their exponentials are 0 and adding 0 changes no sum (the lock-step kernel computes exp2(-inf) for them: the same bits)
+                const float v0 = (g == 0) ? rbf(s[kt][0]) : -INFINITY;
+                s[kt][0] = v0;
+                mx4[kt & 3] = fmaxf(mx4[kt & 3], v0);
+                continue;
             }
+            const uint32_t w0 = pack2bf(s[kt][0], s[kt][1]), w1 = pack2bf(s[kt][2], s[kt][3]);
+            const float v0 = lo_bf(w0), v1 = hi_bf(w0), v2 = lo_bf(w1), v3 = hi_bf(w1);
             s[kt][0] = v0; s[kt][1] = v1; s[kt][2] = v2; s[kt][3] = v3;
             mx4[kt & 3] = fmaxf(fmaxf(fmaxf(fmaxf(mx4[kt & 3], v0), v1), v2), v3);   // (two v_max3_f32 per key tile; max is exact in any order)
         }
@@ -911,7 +918,9 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int kt = 2 * kk + u;
-                    if (kt < VNT) {
+                    if (kt == VNT - 1) {
+                        w[2 * u] = pack2bf(__builtin_amdgcn_exp2f(fmaf(s[kt][0], L2E, nmx)), 0.f);
+                    } else if (kt < VNT) {
                         const f32x2 a0 = __builtin_elementwise_fma((f32x2){s[kt][0], s[kt][1]}, l2, nm2);
                         const f32x2 a1 = __builtin_elementwise_fma((f32x2){s[kt][2], s[kt][3]}, l2, nm2);
                         w[2 * u] = pack2bf(__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1]));
@@ -924,6 +933,12 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
             float sum = 0.f;                                 // (one chain in (kt, r) order, like the other kernels: bit-identical rows)
 #pragma unroll
             for (int kt = 0; kt < VNT; ++kt) {
+                if (kt == VNT - 1) {                         // (one element: see above)
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][0], L2E, nmx));
+                    s[kt][0] = e;
+                    sum += e;
+                    continue;
+                }
                 const f32x2 a0 = __builtin_elementwise_fma((f32x2){s[kt][0], s[kt][1]}, (f32x2){L2E, L2E}, (f32x2){nmx, nmx});
                 const f32x2 a1 = __builtin_elementwise_fma((f32x2){s[kt][2], s[kt][3]}, (f32x2){L2E, L2E}, (f32x2){nmx, nmx});
                 const float arg[4] = {a0[0], a0[1], a1[0], a1[1]};
@@ -940,6 +955,12 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
 #pragma unroll
             for (int kk = 0; kk < VKK; ++kk) {
                 uint4 pw;
+                if (2 * kk == VNT - 1) {                     // keys 256 (this lane group's first) .. 287
+                    pw.x = pack2bf(s[2 * kk][0] * inv, 0.f);
+                    pw.y = pw.z = pw.w = 0u;
+                    pf[kk] = __builtin_bit_cast(bf16x8, pw);
+                    continue;
+                }
                 pw.x = pack2bf(s[2 * kk][0] * inv, s[2 * kk][1] * inv);
                 pw.y = pack2bf(s[2 * kk][2] * inv, s[2 * kk][3] * inv);
                 pw.z = pw.w = 0u;                            // (keys 272..287 do not exist: P = 0)
