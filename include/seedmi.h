@@ -67,7 +67,7 @@ int seedmi_check_device(void);
  * 4 = sixteen-wave kernel with "flash" normalisation (P rounded to half BEFORE the division by the row sum): faster, but NOT
  * bit-compatible with 0-3 - it moves a rounding point of eva_vit.py:139-156 by about 0.8 bf16 ulp rms, token ids form their own equality group |
  * 5 = kernel 3 with the two halves of the workgroup one phase apart (softmax of one half next to the MFMA / LDS phases of the other),
- * wave priorities per phase and - for >= 64 images on a full launch - all heads of an image on one XCD ("attn_xcd", 0|1, default 1):
+ * wave priorities per phase and - on a full launch, i.e. from 16 images - all heads of an image on one XCD ("attn_xcd", 0|1, default 1):
  * the DEFAULT since round 4, bit-identical to 3 | 6 = kernel 4 in that form, bit-identical to 4 | 7 = 5 without the priorities (A/B)).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
  * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
 int seedmi_set_option(const char* key, int value);

@@ -1277,8 +1277,9 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
         }
         const dim3 blk16(64 * V16_WAVES);
         if (g_attn_vit >= 5) {
-            // XCD-aware item walk where it balances: a full launch (one workgroup per CU, CUs a multiple of 8) and >= 8 images per XCD
-            p.xcd_map = (g_attn_xcd.load(std::memory_order_relaxed) && grid == n_cu && n_cu % 8 == 0 && batch >= 64) ? 1 : 0;
+            // XCD-aware item walk on a full launch (one workgroup per CU, CUs a multiple of 8); measured from 16 images up: 20.1 vs 24.7 us at 16,
+            // 30.7 vs 35.9 at 32, 52.7 vs 60.7 at 63 (profiles/r04_call26_attention_xcd_walk_small_batches.log)
+            p.xcd_map = (g_attn_xcd.load(std::memory_order_relaxed) && grid == n_cu && n_cu % 8 == 0 && batch >= 16) ? 1 : 0;
             static bool attr16s_dev[SEEDMI_MAX_DEVICES] = {};
             if (!attr16s_dev[dev]) {
                 (void)hipFuncSetAttribute((const void*)attn_vit16s_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);

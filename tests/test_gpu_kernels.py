@@ -500,7 +500,7 @@ DEFAULT_ATTN_VIT = 5          # the library's default ViT attention kernel (seed
 @pytest.mark.parametrize("B,H,hd,nq,nk,causal", [
     (3, 16, 88, 257, 257, False),     # ViT
     (40, 16, 88, 257, 257, False),    # ViT, more items than CUs (persistent kernel walks > 1 item per workgroup)
-    (72, 16, 88, 257, 257, False),    # ViT, >= 64 images: the staggered kernel's XCD-aware item walk (9 images per XCD: 4.5 rounds of its 32 workgroups)
+    (72, 16, 88, 257, 257, False),    # ViT, uneven rounds of the staggered kernel's XCD-aware item walk (9 images per XCD: 4.5 rounds of its 32 workgroups; 40 images: 5 per XCD)
     (2, 3, 88, 100, 100, False),
     (2, 4, 88, 17, 17, False),        # small ViT (NKP=32 path)
     (5, 12, 64, 32, 32, True),        # Q-Former causal self-attention
