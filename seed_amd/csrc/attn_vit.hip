@@ -748,6 +748,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
     // wave - above PV above QK^T.  Without them the hardware's oldest-first arbitration lets group A win every slot (its QK^T 3.0 k cycles
     // against B's 6.1 k, softmax 4.2 k against 8.4 k).  Measured at B = 128 (profiles/r04_call20_attention_priorities.log), {QK^T, softmax,
     // PV} = none 118.4 us | {3,2,1} 116.9 | {2,3,1} 116.7 | {3,1,2} 119.9 | {1,3,2} 114.3 | {1,2,3} 117.7.
+    // Second sweep around the winner (r04_call27_attention_priorities_2.log): {1,3,2} 113.6 | {0,3,1} 113.7 | {1,3,3} 115.0 | {1,2,2} 115.4 | {2,3,3} 115.4 | {1,3,1} 116.4.
     constexpr bool PRS = (MODE & 4) == 0;
     // (measured and removed, profiles/r04_call24_attention_last_tile.log: the side row's scores in group A's QK^T slot - the shortest phase of
     // the three - with two side rows in LDS taken in turn: 121.2 us against 112.7)
