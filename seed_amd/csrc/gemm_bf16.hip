@@ -1764,6 +1764,12 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
     if (variant == 257 && EPI != EPI_SWIGLU && EPI != EPI_PATCH_EMBED) return launch_gemm256k<EPI>(p, s, sk_ws, sk_ws_bytes);
     if (variant == 233 && EPI != EPI_SWIGLU && EPI != EPI_PATCH_EMBED) return launch_gemm256t<EPI>(p, s, sk_ws, sk_ws_bytes);   // two-phase K-tile on 32x32x16
     if (variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
+    if (variant == 129 && (EPI == EPI_BIAS || EPI == EPI_NONE)) return launch_gemm128x256<EPI>(p, s);   // 128x256x32, two 4-wave workgroups per CU (round 4 experiment)
+    if constexpr (EPI == EPI_BIAS) {                                 // timing-only ablations of it
+        if (variant == 130) return launch_gemm128x256<EPI, 1>(p, s);
+        if (variant == 131) return launch_gemm128x256<EPI, 3>(p, s);
+        if (variant == 132) return launch_gemm128x256<EPI, 7>(p, s);
+    }
     if (variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
 #endif
     const bool use256 = variant == 256 || (variant == 0 && big);
@@ -1784,7 +1790,7 @@ static int auto_group_m(int N, int K) {
 
 extern "C" int seedmi_set_option(const char* key, int value) {
 #ifdef SEEDMI_DEVTOOLS
-    const bool dev_variant = value == 232 || value == 233 || value == 255 || value == 257;
+    const bool dev_variant = (value >= 129 && value <= 132) || value == 232 || value == 233 || value == 255 || value == 257;
 #else
     const bool dev_variant = false;
 #endif
