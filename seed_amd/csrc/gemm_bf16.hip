@@ -1769,6 +1769,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
         if (variant == 130) return launch_gemm128x256<EPI, 1>(p, s);
         if (variant == 131) return launch_gemm128x256<EPI, 3>(p, s);
         if (variant == 132) return launch_gemm128x256<EPI, 7>(p, s);
+        if (variant == 133) return launch_gemm128x256<EPI, 8>(p, s);
     }
     if (variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
 #endif
@@ -1790,7 +1791,7 @@ static int auto_group_m(int N, int K) {
 
 extern "C" int seedmi_set_option(const char* key, int value) {
 #ifdef SEEDMI_DEVTOOLS
-    const bool dev_variant = (value >= 129 && value <= 132) || value == 232 || value == 233 || value == 255 || value == 257;
+    const bool dev_variant = (value >= 129 && value <= 133) || value == 232 || value == 233 || value == 255 || value == 257;
 #else
     const bool dev_variant = false;
 #endif
