@@ -131,6 +131,14 @@ def test_argument_validation_returns_status_codes_and_messages():
     assert l.seedmi_detokenize(None, fake, 1, fake, None, fake, 0, None) == E_SHAPE
     assert l.seedmi_set_option(b"no_such_option", 1) == E_SHAPE and "no_such_option" in err()
     assert l.seedmi_set_option(b"tokenize_streams", 9) == E_SHAPE
+    # the ViT attention's kernel selection and the round-4 options documented in the header: accepted ranges, defaults restored
+    for v in range(0, 8):
+        assert l.seedmi_set_option(b"attn_vit", v) == 0
+    assert l.seedmi_set_option(b"attn_vit", 8) == E_SHAPE and l.seedmi_set_option(b"attn_vit", -1) == E_SHAPE
+    assert l.seedmi_set_option(b"attn_vit", 5) == 0                      # the default (staggered 16-wave kernel)
+    assert l.seedmi_set_option(b"attn_xcd", 0) == 0 and l.seedmi_set_option(b"attn_xcd", 2) == E_SHAPE and l.seedmi_set_option(b"attn_xcd", 1) == 0
+    assert l.seedmi_set_option(b"gemm_sched", 81) == 0 and l.seedmi_set_option(b"gemm_sched", 8273) == 0
+    assert l.seedmi_set_option(b"gemm_sched", 16384) == E_SHAPE and l.seedmi_set_option(b"gemm_sched", -1) == 0
     with pytest.raises(lib.SeedmiError, match="unknown option"):
         lib.check(l.seedmi_set_option(b"gemm", 7), "seedmi_set_option")
 
