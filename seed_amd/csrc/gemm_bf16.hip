@@ -879,6 +879,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // uniform_ktile_body.log): QKV +0.2..0.3 %, proj +0.2..0.4 %, fc1 +0.2..0.4 %, fc2 +1.0..1.4 %, the tokenize pass +0.5 % both times
     // (122.09 vs 122.73 ms, 120.11 vs 120.73 ms).  Small, and the only schedule change of round 4 that did not lose: the default (8273 = 81 + 8192).
     constexpr bool UNIFORM = TWOPH && (SCHED & 8192) != 0;
+    // (round 4 call 32, timing-only probe, removed: W read as if packed request-major at load time - every W request 1 KiB contiguous instead of 8 rows x 128
+    //  bytes at a stride of 2 K bytes: QKV / proj / fc1 / fc2 1245.8 / 967.9 / 1197.4 / 1241.0 against 1242.2 / 964.0 / 1194.1 / 1235.2 TF, +0.3..0.5 %: not worth a
+    //  weight format - profiles/r04_call32_gemm_w_packed_probe.log)
     // (round 4 call 28, measured and removed: s_setprio 1 during a wave's LOAD sections - fragment reads + LDS-DMA requests - and 0 during its MFMA
     //  sections, the reverse of SEEDMI_GEMM_PRIO: QKV / proj / fc1 / fc2 1194.8 / 945.4 / 1156.7 / 1199.8 against 1194.3 / 944.7 / 1157.4 / 1202.5 TF, the
     //  pass 126.01 vs 125.90 ms - nothing either way: profiles/r04_call28_gemm_load_section_priority.log)
