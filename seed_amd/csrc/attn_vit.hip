@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
 //     slot 3k+1   A: softmax(k)     B: QK^T(k)          V(k) requested at the slot's start      (V(k-1) was last read in slot 3k)
 //     slot 3k+2   A: PV(k)          B: softmax(k)       K(k+1), Q(k+1) requested at its start   (K(k), Q(k) were last read in slot 3k+1)
 // so in two slots of three a VALU-bound phase runs next to an LDS / MFMA-bound one, with two waves of each kind on every SIMD.  One s_barrier
-// per slot; every request has one slot (~5 k cycles) of flight before the barrier that publishes it.  The three LDS images, the staging code,
+// per slot; every request has one slot (~5 k cycles) of flight before the barrier that publishes it.  The three LDS images (their request addresses are formed more cheaply: stage2 below),
 // the side path of row 256 (scores by an A wave in slot 3k+1, its PV by a B wave in slot 3k+3) are those of attn_vit16_kernel.
 // Measured at B = 128, bit-identical to the lock-step kernel on every element (first launch and 20-launch bursts, three batch sizes;
 // profiles/r04_call14_ .. r04_call23_*attention*.log), us per launch, lock-step kernel (attn_vit = 3) on the same box in brackets:
