@@ -170,6 +170,43 @@ def measured_ceilings():
     return out
 
 
+def vit_attention_leg(images=128):
+    """SURVEY row a4 as the tokenize path issues it: ONE launch of the ViT attention for a sub-batch of 128 images (16 heads x 88, 257 tokens,
+    packed q|k|v rows as the QKV GEMM writes them), timed in isolation with HIP events.  Its roofline is bytes (Q, K, V in, O out), not flops."""
+    from seed_amd import lib as L
+    lib = L.load()
+    H, hd, N = 16, 88, 257
+    C = H * hd
+    g = torch.Generator(device="cuda").manual_seed(7)
+    qkv = torch.randn(images * N, 3 * C, device="cuda", generator=g).bfloat16()
+    out = torch.empty(images * N, C, device="cuda", dtype=torch.bfloat16)
+
+    def run():
+        L.check(lib.seedmi_attention_bf16(L.ptr(qkv), 3 * C, L.ptr(qkv[:, C:]), 3 * C, L.ptr(qkv[:, 2 * C:]), 3 * C, L.ptr(out), C,
+                                          images, H, hd, N, N, hd ** -0.5, 0, 1, L.stream_ptr()), "attention")
+    # (a burst between two events: a pair of events around a single ~0.1 ms launch adds ~15 % of event / launch latency to it)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    bursts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        bursts.append(e0.elapsed_time(e1) / 20)
+    bursts.sort()
+    avg_ms, med_ms = sum(bursts) / len(bursts), bursts[len(bursts) // 2]
+    flops = 4.0 * images * H * N * N * hd
+    nbytes = images * N * C * 2 * 4
+    return {"kernel": "attn_vit16s_kernel (staggered 16-wave kernel, XCD-aware item walk)", "images": images, "avg_launch_us": round(avg_ms * 1e3, 1),
+            "median_launch_us": round(med_ms * 1e3, 1), "timing": "5 bursts of 20 back-to-back launches between two HIP events", "tflops": round(flops / (avg_ms * 1e-3) / 1e12, 1),
+            "roofline": {"bound": "hbm", "achieved": round(nbytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes}}
+
+
 def _reference_tokenizer():
     """The reference's OWN modules (models/seed_qformer/*.py), imported through oracle/ref_shims.py from /root/reference where that tree
     exists and from the bytecode oracle/build_ref.py compiled into oracle/_ref/ otherwise (that directory travels to the GPU box)."""
@@ -407,6 +444,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_images) if (world == 1 and not args.no_cpu_baseline) else None
         del eng, images
         torch.cuda.empty_cache()
+        try:
+            extra["vit_attention"] = vit_attention_leg()
+        except Exception as e:
+            extra["vit_attention"] = {"error": repr(e)[:200]}
         try:
             extra["measured_ceilings"] = measured_ceilings()
         except Exception as e:
