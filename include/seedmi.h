@@ -41,9 +41,12 @@ extern "C" {
 /* Bumped whenever an existing entry point changes its argument list or a struct in this header changes layout (new entry points alone
  * do not bump it).  1: round 1.  2: seedmi_sample_token_bf16 / seedmi_rope_kv_append / seedmi_llama_decode_attention_bf16 gained an
  * argument before `stream`, seedmi_vit_layer_t grew by six pointers (LayerNorm fold).  3: seedmi_gemm_ext_t grew (tile-span statistics).
+ * 4 (round 5): the calibration kernels seedmi_bench_stream_read / seedmi_bench_mfma_bf16 left the library (tools/calib/libseedcal.so), llama /
+ * split-K workspaces carry a tag written by seedmi_llama_workspace_init / seedmi_gemm_skinny_workspace_init which the status calls require,
+ * the llama workspace lost its stream-K region (smaller seedmi_llama_workspace_bytes), seedmi_set_option lost its history / A-B keys.
  * A caller compiled against this header must check  seedmi_version() == SEEDMI_ABI_VERSION  before its first call: a mismatch
  * means arguments and struct strides no longer line up (silent corruption, not an error).  seed_amd/lib.py does. */
-#define SEEDMI_ABI_VERSION 3
+#define SEEDMI_ABI_VERSION 4
 
 int seedmi_version(void);
 const char* seedmi_last_error(void);
@@ -224,8 +227,11 @@ int seedmi_gemm_skinny_norm_bf16(int M, int N, int K, const void* A, int a_packe
  * workspace == NULL, M > 32, a_packed == 0 or seedmi_set_option("skinny_splitk", 0) select the kernel of seedmi_gemm_skinny_norm_bf16;
  * all forms give the same values up to the order of the fp32 K summation. */
 size_t seedmi_gemm_skinny_workspace_bytes(void);
-/* Reads (and, once reported, clears) the sticky error word of such a workspace: SEEDMI_OK, or SEEDMI_E_HIP with the workgroup that gave up
- * in seedmi_last_error().  SYNCHRONISES `stream` (one 4-byte copy to the host): call it after a decode loop, not inside one. */
+/* Once after allocation (instead of the hipMemset; stream-ordered, no synchronisation): zeroes the flag words and the error word and writes
+ * a tag into word 1022, by which seedmi_gemm_skinny_ws_status tells an initialised workspace from uninitialised memory. */
+int seedmi_gemm_skinny_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+/* Reads (and, once reported, clears) the sticky error word of such a workspace: SEEDMI_OK, SEEDMI_E_HIP with the workgroup that gave up
+ * in seedmi_last_error(), or SEEDMI_E_SHAPE for a workspace that never saw seedmi_gemm_skinny_workspace_init (no tag).  SYNCHRONISES `stream` (one 4-byte copy to the host): call it after a decode loop, not inside one. */
 int seedmi_gemm_skinny_ws_status(void* workspace, size_t workspace_bytes, void* stream);
 int seedmi_gemm_skinny_norm_ws_bf16(int M, int N, int K, const void* A, int a_packed, const void* W_packed, float rms_eps,
                                     const void* residual, int ldr, int epilogue, void* C, int ldc, int c_packed, void* x_packed_out,
@@ -394,6 +400,9 @@ typedef struct {
  * every step clears its hand-off flags itself, the sticky error word (32-bit word 1023) is only ever cleared by seedmi_llama_decode_status;
  * prefills never touch the area, so one workspace may serve prefills and decode steps alike. */
 size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, int batch, int T);
+/* Once after allocating a llama workspace of any (batch, T) (stream-ordered): seedmi_gemm_skinny_workspace_init on its split-K area.  A
+ * workspace that skips this still computes correctly from all-zero memory, but seedmi_llama_decode_status refuses it (SEEDMI_E_SHAPE). */
+int seedmi_llama_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 /* LlamaForCausalLM.forward, eval, use_cache (llama_xformer.py:661-743): ids/pos int64 [B,T]; appends to the static
  * KV cache at past_len; logits bf16 [B*T_out, ldl] where T_out = T (all positions, reference behaviour) or 1
  * (last position only, decode fast path) depending on last_only. */

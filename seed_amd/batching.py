@@ -37,7 +37,7 @@ class ContinuousBatcher:
         self.uniforms = torch.zeros(self.chunk, self.B, dtype=torch.float32, device=dev) if top_p > 0.0 else None
         self.logits = torch.empty(self.B, engine.vocab_pad, dtype=torch.bfloat16, device=dev)
         # the step's workspace is baked into the captured graph: owned here, never reallocated; prefills use their own
-        self._ws = torch.zeros(self.lib.seedmi_llama_workspace_bytes(C.byref(engine.w), self.B, 1), dtype=torch.uint8, device=dev)
+        self._ws = engine.new_workspace(self.lib.seedmi_llama_workspace_bytes(C.byref(engine.w), self.B, 1))
         self._ws_prefill = None
         self._graph = None
         self._slot_w = {}
@@ -81,7 +81,7 @@ class ContinuousBatcher:
             else:
                 req["max_new"] = min(req["max_new"], room)
         self._graph, self._slot_w = None, {}
-        self._ws = torch.zeros(self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), self.B, 1), dtype=torch.uint8, device=eng.device)
+        self._ws = eng.new_workspace(self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), self.B, 1))
         self._ws_prefill = None
         self._generation = eng.cache_generation
 
@@ -145,6 +145,18 @@ class ContinuousBatcher:
                 return True
         return False
 
+    def abort(self):
+        """Drop EVERYTHING this batcher holds - waiting requests, requests already prefilled into slots, finished results nobody collected -
+        and return every slot.  For the caller whose run() raised midway: without it the next run() would keep decoding the
+        failed call's orphaned slots and hand their stale ids to whoever asks next."""
+        self.waiting.clear()
+        for s in list(self.active):
+            self.active.pop(s)
+            self.inc[s:s + 1].fill_(0)
+            self.lens[s:s + 1].fill_(0)
+            self.free.append(s)
+        self.done = {}
+
     @property
     def idle(self) -> bool:
         return not self.waiting and not self.active
@@ -171,7 +183,7 @@ class ContinuousBatcher:
         lg = torch.empty(1, eng.vocab_pad, dtype=torch.bfloat16, device=eng.device)
         need = self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), 1, T0)
         if self._ws_prefill is None or self._ws_prefill.numel() < need:
-            self._ws_prefill = torch.empty(need, dtype=torch.uint8, device=eng.device)
+            self._ws_prefill = eng.new_workspace(need)
         ws = self._ws_prefill
         with torch.cuda.device(eng.device):
             L.check(self.lib.seedmi_llama_forward_io(C.byref(self._slot_weights(s)), L.ptr(ids), None, L.ptr(pos), 1, T0, 0, None, 1,

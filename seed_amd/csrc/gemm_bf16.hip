@@ -779,7 +779,18 @@ constexpr int RING_W = 4 * HALF_BYTES;            // the W region starts behind 
 
 // Segment list (tile, first K-iteration, end K-iteration) of this workgroup, written to LDS (see gemm256_kernel): the data-parallel
 // tiles of its XCD chunk, then - with a stream-K workspace - its share of the chunk's last 2..3 rounds, walked backwards.
+// (PACKED: the tile entry is (m-tile << 12) | n-tile instead of the tile's index in the grouped order - no division between two tiles)
+template <bool PACKED = false>
 SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid) {
+    auto coords = [&](int t) {
+        if (!PACKED) return t;
+        const int gsize = p.group_m * p.tiles_n;
+        const int gid = t / gsize;
+        const int first_m = gid * p.group_m;
+        const int gm = min(p.tiles_m - first_m, p.group_m);
+        const int in_g = t - gid * gsize;
+        return ((first_m + in_g % gm) << 12) | (in_g / gm);
+    };
     const int nt = p.tiles_m * p.tiles_n;
     int n_seg = 0;
     const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
@@ -799,13 +810,13 @@ SEEDMI_DEVINL int build_segments(const GemmParams& p, int nk, int* segs, int tid
         sk_hi = idx + 1 == G ? I : cut(idx + 1);
     }
     if (n_dp > MAX_SEGS - 5) n_dp = MAX_SEGS - 5;   // (the launcher keeps nt / grid below this)
-    for (int j = tid; j < n_dp; j += 512) { segs[3 * j] = cs + idx + j * G; segs[3 * j + 1] = 0; segs[3 * j + 2] = nk; }
+    for (int j = tid; j < n_dp; j += 512) { segs[3 * j] = coords(cs + idx + j * G); segs[3 * j + 1] = 0; segs[3 * j + 2] = nk; }
     n_seg = n_dp;
     while (sk_it < sk_hi) {                         // <= 4 segments, from the END of the range (uniform)
         const int tl = (sk_hi - 1) / nk;
         const int ke = sk_hi - tl * nk;
         const int kb = max(0, ke - (sk_hi - sk_it));
-        if (tid == 0) { segs[3 * n_seg] = sk_tile0 + tl; segs[3 * n_seg + 1] = kb; segs[3 * n_seg + 2] = ke; }
+        if (tid == 0) { segs[3 * n_seg] = coords(sk_tile0 + tl); segs[3 * n_seg + 1] = kb; segs[3 * n_seg + 2] = ke; }
         sk_hi -= ke - kb;
         ++n_seg;
     }
@@ -879,6 +890,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // uniform_ktile_body.log): QKV +0.2..0.3 %, proj +0.2..0.4 %, fc1 +0.2..0.4 %, fc2 +1.0..1.4 %, the tokenize pass +0.5 % both times
     // (122.09 vs 122.73 ms, 120.11 vs 120.73 ms).  Small, and the only schedule change of round 4 that did not lose: the default (8273 = 81 + 8192).
     constexpr bool UNIFORM = TWOPH && (SCHED & 8192) != 0;
+    // bit 14 (uniform two-phase K-tile, round 5): SEAM - the K loop never stops requesting at a tile boundary.  The 14 requests per tile that the
+    // uniform body issues beyond its segment (bit 13 lets them re-fetch the last K-tile into dead ring slots) are exactly the next tile's prologue
+    // (its first K-tile in full, W and the mh0 rows of its second), so they are pointed at the NEXT tile instead: the tile of a request is a
+    // wave-uniform buffer descriptor (base = the tile's first row, num_records = what is left of the matrix: rows beyond M / N are out of range
+    // and never fetched), the lane offsets inside a tile never change, and the switch from this tile's descriptor to the next one's is two
+    // scalar selects per K-tile - no branch in the body, no VALU, no per-tile address set-up, no prologue between the K loop and the epilogue.
+    // Applies to whole-tile segments with an even number of K-tiles (ring slot parity carries over) and finished LayerNorm statistics; anything
+    // else takes the prologue path of bit 13 inside the same kernel.  Same k-ordered accumulation chain per element: bit-identical.
+    constexpr bool SEAM = UNIFORM && (SCHED & 16384) != 0;
+    // bit 15 (on top of the seam): PEEL - a tile's output stores drain UNDER the next tile's first two K-tiles.  vmcnt retires in order and counts
+    // stores, so the steady-state waits of a tile's first K-tile also wait for 10 of the 16 output stores the wave issued a moment ago (the K loop
+    // of a QKV tile takes ~5 k cycles longer than 22 steady-state K-tiles; with the stores ablated the GEMM is 9 % faster).  With the seam every
+    // request of the next tile's first TWO K-tiles is issued before the stores (the last two mh1 pieces right behind the K loop), so their waits can
+    // let the 16 stores stay in flight - but a wait count is an immediate: the two K-tiles are peeled into bodies of their own (mode 1 / 2 of
+    // ktile2: straight-line copies that differ in three immediates and one absent request - no branch in any body), entered only through a seamed
+    // boundary.  Round 4's "store-tolerant waits" tried the counts with branches inside the one body and lost 3 %; the same round later measured
+    // that such a branch alone costs the loop 2-7 %.  A wave that does not issue exactly its 16 stores (ragged tile edge) drains its queue instead.
+    constexpr bool PEEL = SEAM && (SCHED & 32768) != 0 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESIDUAL);
     // (round 4 call 32, timing-only probe, removed: W read as if packed request-major at load time - every W request 1 KiB contiguous instead of 8 rows x 128
     //  bytes at a stride of 2 K bytes: QKV / proj / fc1 / fc2 1245.8 / 967.9 / 1197.4 / 1241.0 against 1242.2 / 964.0 / 1194.1 / 1235.2 TF, +0.3..0.5 %: not worth a
     //  weight format - profiles/r04_call32_gemm_w_packed_probe.log)
@@ -921,7 +950,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr int STAT_OFF = SCRATCH_OFF + SCRATCH_BYTES;
     constexpr bool FOLD_IN = LNF && EPI != EPI_BIAS_RESIDUAL;
     int fold_par = 0;                                               // operand set the NEXT prologue fills
-    const int n_seg = build_segments(p, nk, segs, tid);
+    const int n_seg = build_segments<SEAM>(p, nk, segs, tid);
     if (n_seg == 0) return;                                            // uniform for the whole workgroup
     if (EPI == EPI_BIAS_GELU) load_gelu_lut(smem + 2 * KT_BYTES, tid, 512);   // activation table behind the operand ring
     __syncthreads();
@@ -944,7 +973,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, -1, 0x00020000);      // (raw: no stride, 4 GiB range)
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, -1, 0x00020000);
     // LDS-DMA sources of a tile: every wave copies rows [16w, 16w+16) of each half-tile (2 pieces of 8 rows)
+    // SEAM: the tile of a request lives in a wave-uniform descriptor; cur = the tile being computed, nxt = where the requests beyond its
+    // last K-tile go (the next tile; the same tile again - its last K-tile, as in bit 13 - where the boundary is not seamed)
+    __amdgpu_buffer_rsrc_t curA = rsA, curW = rsW, nxtA = rsA, nxtW = rsW;
+    int nkb = 0, nke = 1;                               // K-tiles [nkb, nke) of the tile behind nxtA / nxtW
+    auto tile_desc = [&](int tm0, int tn0, __amdgpu_buffer_rsrc_t& dA, __amdgpu_buffer_rsrc_t& dW) {
+        // (bytes left below the tile's first row: < 2^32, the entry point keeps every matrix below 2^31 elements)
+        dA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)tm0 * (size_t)p.lda), 0,
+                                               (int)((uint32_t)(p.M - tm0) * (uint32_t)p.lda * 2u), 0x00020000);
+        dW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)tn0 * (size_t)p.ldw), 0,
+                                               (int)((uint32_t)(p.N - tn0) * (uint32_t)p.ldw * 2u), 0x00020000);
+    };
+    if (SEAM) {                                         // lane offsets inside ANY tile: formed once
+        const int ln = fresh_lane();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 128 * h + 16 * wave + 8 * j + (ln >> 3);
+                const int rowA = 128 * h + 64 * j + 8 * wave + (ln >> 3);
+                const int cs = ln & 7;
+                offA[h][j] = 2u * ((uint32_t)rowA * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(rowA)));
+                offW[h][j] = 2u * ((uint32_t)row * (uint32_t)p.ldw + 8u * (uint32_t)(cs ^ swzW(row)));
+            }
+    }
     auto set_tile = [&](int t) {
+        if (SEAM) {                                     // t = (m-tile << 12) | n-tile (build_segments<true>)
+            m0 = (t >> 12) * B2;
+            n0 = (t & 4095) * B2;
+            tile_desc(m0, n0, curA, curW);
+            return;
+        }
         const int gsize = p.group_m * p.tiles_n;
         const int gid = t / gsize;
         const int first_m = gid * p.group_m;
@@ -979,11 +1038,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // one 16-byte-per-lane request of A / W: lane byte offset `off` (set_tile), K origin k0 (elements), LDS destination of the wave
     auto dmaA = [&](uint32_t off, int k0, char* dst) {
         if (FLATDMA) glds16(p.A + ((off >> 1) + (uint32_t)k0), dst);
-        else glds16_buf(rsA, off, 2u * (uint32_t)k0, dst);
+        else glds16_buf(SEAM ? curA : rsA, off, 2u * (uint32_t)k0, dst);
     };
     auto dmaW = [&](uint32_t off, int k0, char* dst) {
         if (FLATDMA) glds16(p.W + ((off >> 1) + (uint32_t)k0), dst);
-        else glds16_buf(rsW, off, 2u * (uint32_t)k0, dst);
+        else glds16_buf(SEAM ? curW : rsW, off, 2u * (uint32_t)k0, dst);
+    };
+    // SEAM: the requests of K-tile index q of the current walk: inside the segment -> this tile, beyond it -> K-tile nkb + (q - ke) of the tile
+    // behind nxtA / nxtW.  Scalar selects only.
+    auto seam_A_rows = [&](int q, int ke, int j) {      // this wave's mh0 (j = 0) / mh1 (j = 1) piece of both A half-tiles into ring slot q & 1
+        const bool over = q >= ke;
+        const uint32_t koff = (uint32_t)(over ? min(nkb + (q - ke), nke - 1) : q) * (uint32_t)(2 * BK);
+        const __amdgpu_buffer_rsrc_t d = over ? nxtA : curA;
+        char* base = smem + (q & 1) * RING_SLOT + wave * 1024 + j * 8192;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) glds16_buf(d, offA[h][j], koff, base + h * HALF_BYTES);
+    };
+    auto seam_W = [&](int q, int ke) {
+        const bool over = q >= ke;
+        const uint32_t koff = (uint32_t)(over ? min(nkb + (q - ke), nke - 1) : q) * (uint32_t)(2 * BK);
+        const __amdgpu_buffer_rsrc_t d = over ? nxtW : curW;
+        char* base = smem + RING_W + (q & 1) * RING_SLOT + wave * 2048;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16_buf(d, offW[h][j], koff, base + h * HALF_BYTES + j * 1024);
     };
     auto stageA = [&](int kt) {            // both A half-tiles of K-tile kt
         char* base = smem + (kt & 1) * RING_SLOT + (TWOPH ? wave * 1024 : wave * 2048);
@@ -1022,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         for (int h = 0; h < 2; ++h) dmaW(offW[h][j], k0, base + h * HALF_BYTES + j * 1024);
     };
     // prologue loads of a segment: its first K-tile (A and W) and, already in flight behind it, W of the second
-    auto issue_prologue = [&](int kb, int ke) {
+    auto issue_fold_pieces = [&]() {
         if (FOLD_IN) {
             // the tile's fold operands travel with its first K-tile, as its OLDEST LDS-DMA requests (1 KiB pieces dealt round-robin: wave w
             // takes pieces w, w + 8, ...; with finished statistics that is one piece for waves 0-3 and none for waves 4-7): complete, and
@@ -1052,6 +1131,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             }
             fold_par ^= 1;
         }
+    };
+    auto issue_prologue = [&](int kb, int ke) {
+        issue_fold_pieces();
         stageA(kb);
         stageW(kb);
         if (kb + 1 < ke) {
@@ -1298,7 +1380,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     };
 
     // ---- TWOPH: one K-tile in two phases of 32 MFMAs (see the SCHED notes above the kernel)
-    auto ktile2 = [&](auto slot_tag, const int kt, const int kb, const int ke) {
+    auto ktile2 = [&](auto slot_tag, auto mode_tag, const int kt, const int kb, const int ke) {
+        // MODE (PEEL): 0 = steady state; 1 / 2 = first / second K-tile of a tile entered through a seamed boundary: every request of these two
+        // K-tiles is older than the previous tile's 16 output stores, which may still be in flight
+        constexpr int MODE = decltype(mode_tag)::value;
         constexpr int SLOT = decltype(slot_tag)::value; // 0 / 1: the ring slot of K-tile kt, known at compile time; -1: kt & 1
         const int slot = SLOT >= 0 ? SLOT : (kt & 1);
         const char* pa0 = smem + rdA0 + slot * RING_SLOT;                    // k-step 0
@@ -1308,7 +1393,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // ================= phase a: rows mh0 x (nh0, nh1) =================
         // A-mh1(kt), requested in phase a of kt-1, is read in phase b: everything but the six requests of phase b of kt-1 must have landed
         // (the segment's first K-tile came with the prologue and was waited for at the tile's opening)
-        if (UNIFORM) {
+        if (MODE == 1) {
+            // (this K-tile was complete before the stores went out: the epilogue's hook waited for it)
+        } else if (MODE == 2) {
+            asm volatile("s_waitcnt vmcnt(22)" ::: "memory");         // A-mh1 of this K-tile landed; behind it: 16 stores + the six requests of phase b of K-tile 0
+        } else if (UNIFORM) {
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // (first K-tile: the opening wait left at most six in flight already)
         } else if (kt > kb) {
             if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1321,7 +1410,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + t * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + t * 2048); }
         // mh1 rows of the other parity: last read in phase b of kt-1, retired before its barrier
-        if (UNIFORM) stageA_rows(kt + 1, 1, min(kt + 1, ke - 1));
+        if (MODE == 1) {}                               // (A-mh1 of the second K-tile was requested right behind the previous K loop)
+        else if (SEAM) seam_A_rows(kt + 1, ke, 1);
+        else if (UNIFORM) stageA_rows(kt + 1, 1, min(kt + 1, ke - 1));
         else if (kt + 1 < ke) stageA_rows(kt + 1, 1);
         if (!LATEWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SEEDMI_SCHED_FENCE();
@@ -1343,10 +1434,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         // ================= phase b: rows mh1 x the same W fragments =================
         // W(kt+1) and A-mh0(kt+1) (phase b of kt-1, or the prologue) are read in phase a of kt+1: only this K-tile's two requests stay in flight
-        if (UNIFORM || kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (MODE == 1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // W and A-mh0 of the second K-tile landed; behind them: its A-mh1 pieces (2) + 16 stores
+        else if (UNIFORM || kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 4; ++t) { fa[t] = *(const bf16x8*)(pa0 + (4 + t) * 2048); fa[4 + t] = *(const bf16x8*)(pa1 + (4 + t) * 2048); }
-        if (UNIFORM) {                                  // this parity's W and mh0 rows were last read in phase a, retired before its barrier
+        if (SEAM) {
+            seam_W(kt + 2, ke);
+            seam_A_rows(kt + 2, ke, 0);
+        } else if (UNIFORM) {                           // this parity's W and mh0 rows were last read in phase a, retired before its barrier
             stageW(kt + 2, min(kt + 2, ke - 1));
             stageA_rows(kt + 2, 0, min(kt + 2, ke - 1));
         } else if (kt + 2 < ke) {
@@ -1373,10 +1468,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
     };
 
+    // SEAM applies to launches of whole tiles with an even number of K-tiles (the ring slot of a K-tile is its index's parity: an even tile
+    // hands the next one the right slots) and finished statistics (partial planes are finalized at a tile's opening, from requests that would
+    // then be the youngest of the seam); everything else keeps the prologue path
+    const bool seam_ok = SEAM && (nk & 1) == 0 && nk >= 2 && p.sk_slabs == nullptr && p.ln_planes == 0;
+    bool peel_now = false;                              // PEEL: this tile was entered through a seamed boundary (peeled first two K-tiles)
     for (;;) {
     const int em0 = m0, en0 = n0;                       // this tile's output origin (m0/n0 move on to the next tile early)
     const int fold_cur = fold_par ^ 1;                  // ... and its fold operand set
     const int kb = s_kb, ke = s_ke;                     // (s_* move on to the next segment before the epilogue)
+    bool seam_more = false, seamed = false;
+    if (SEAM) {
+        // the next segment is looked up BEFORE the K loop: its tile is where this K loop's last requests go
+        seam_more = next_seg(s_tile, s_kb, s_ke);
+        seamed = seam_ok && seam_more && ke - kb >= 2 && s_ke - s_kb >= 2;
+        if (seamed) {
+            tile_desc((s_tile >> 12) * B2, (s_tile & 4095) * B2, nxtA, nxtW);
+            nkb = s_kb; nke = s_ke;
+        } else {                                        // (as bit 13: the last K-tile again, into ring slots nobody reads any more)
+            nxtA = curA; nxtW = curW;
+            nkb = ke - 1; nke = ke;
+        }
+    }
     if (kb > 0) {
         // ---- K tail of a shared tile (always this workgroup's last segment): continue the accumulation of the workgroup in
         //      front of it on this XCD, which published the head at the START of its stream-K range, two tiles' time ago.
@@ -1480,7 +1593,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // (measured and removed, round 4 call 12: the same loop pair-unrolled with compile-time ring slots - segments start on even
         //  K-tiles - compiles with 12-52 B of scratch and runs proj -4.3 %, fc2 -4.6 %, QKV/fc1 equal, the pass -1.9 %:
         //  profiles/r04_call12_uniform_ktile_body.log.  The four v_add per K-tile of the run-time slots are cheaper than two bodies.)
-        for (int kt = kb; kt < ke; ++kt) ktile2(slot_dyn(), kt, kb, ke);
+        using mode_steady = std::integral_constant<int, 0>;
+        int kt = kb;
+        if (PEEL && peel_now) {                        // (wave-uniform, outside the bodies)
+            ktile2(slot_dyn(), std::integral_constant<int, 1>(), kb, kb, ke);
+            ktile2(slot_dyn(), std::integral_constant<int, 2>(), kb + 1, kb, ke);
+            kt = kb + 2;
+        }
+        for (; kt < ke; ++kt) ktile2(slot_dyn(), mode_steady(), kt, kb, ke);
     } else if (!live && TWOPH) {
         // same requests, waits and barriers as ktile2, no fragment reads, no MFMA
         for (int kt = kb; kt < ke; ++kt) {
@@ -1490,13 +1610,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (UNIFORM) stageA_rows(kt + 1, 1, min(kt + 1, ke - 1));
+            if (PEEL && peel_now && kt == kb) {}       // (requested behind the previous K loop; this wave stored nothing and drained its queue)
+            else if (SEAM) seam_A_rows(kt + 1, ke, 1);
+            else if (UNIFORM) stageA_rows(kt + 1, 1, min(kt + 1, ke - 1));
             else if (kt + 1 < ke) stageA_rows(kt + 1, 1);
             SEEDMI_SCHED_FENCE();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
             if (UNIFORM || kt + 1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            if (UNIFORM) {
+            if (SEAM) {
+                seam_W(kt + 2, ke);
+                seam_A_rows(kt + 2, ke, 0);
+            } else if (UNIFORM) {
                 stageW(kt + 2, min(kt + 2, ke - 1));
                 stageA_rows(kt + 2, 0, min(kt + 2, ke - 1));
             } else if (kt + 2 < ke) {
@@ -1562,19 +1687,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
     // every LDS read of this segment is done: start the next segment's prologue loads now so that their latency (and the
     // epilogue's own loads and stores) overlap instead of opening the next tile with an empty pipeline
-    const bool more = next_seg(s_tile, s_kb, s_ke);
+    const bool more = SEAM ? seam_more : next_seg(s_tile, s_kb, s_ke);
     constexpr bool late = SEEDMI_LATE_PROLOGUE != 0;
     auto start_next = [&]() {
         if (more) {
-            set_tile(s_tile);
-            issue_prologue(s_kb, s_ke);
+            if (SEAM && seamed) {
+                // the next tile's first K-tile (and most of its second) was requested by this tile's last two K-tiles: only the tile
+                // origin moves on and the fold operands (needed by the next tile's END) are requested
+                // PEEL: the last two pieces of the next tile's SECOND K-tile (its mh1 rows; their ring rows were last read in phase b of this
+                // tile's last K-tile, two barriers ago for either wave group) - everything its first two K-tiles read is now older than the stores
+                if (PEEL) seam_A_rows(ke + 1, ke, 1);
+                m0 = (s_tile >> 12) * B2;
+                n0 = (s_tile & 4095) * B2;
+                curA = nxtA; curW = nxtW;
+                issue_fold_pieces();
+            } else {
+                set_tile(s_tile);
+                issue_prologue(s_kb, s_ke);
+            }
         }
     };
     // the epilogues call this once: after their own loads have landed, before their first store
     auto hook = [&]() {
         if (late) start_next();
         if (PREWAIT && more) {
-            if (s_ke - s_kb > 1) {
+            if (PEEL && seamed) {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // (the second K-tile's eight requests stay in flight)
+            } else if (s_ke - s_kb > 1) {
                 if (TWOPH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // (the second K-tile's W and A-mh0 requests stay in flight)
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // (the second W's four requests stay in flight)
             } else {
@@ -1622,7 +1761,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
         // (every wave of the workgroup, also those whose span lies beyond N and parked nothing: the combine is a workgroup job)
         if (STATS_OUT && p.stats_by_tile) { stats_pending = true; sp_m0 = em0; sp_n0 = en0; }
+        if (PEEL && seamed) {
+            // the peeled K-tiles' wait counts assume this wave's 16 output stores behind the seam's requests.  A wave at a ragged edge of the
+            // matrix (rows beyond M or a span not wholly inside N: some or all of its stores are skipped) drains its queue instead - then the
+            // counts hold trivially
+            const bool full16 = (en0 + 64 * wn + 64 <= p.N) && (em0 + 128 * wm + 128 <= p.M) && p.skip_epilogue == 0;
+            if (!full16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
+    peel_now = PEEL && seamed && more;
 #ifdef SEEDMI_DEVTOOLS
     if (GSTAMP_ON) { GSTAMP(2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); GSTAMP_STORE(0, 3, 101); }
     ++dbg_tile;
@@ -1707,6 +1854,8 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
 #ifdef SEEDMI_SCHED_ONLY                               // (register-pressure experiments: one variant, short compile)
             case SEEDMI_SCHED_ONLY: return launch_gemm256_sched<EPI, LNF, SEEDMI_SCHED_ONLY>(p, stream, sk_ws, sk_ws_bytes);
 #else
+            case 57425: return launch_gemm256_sched<EPI, LNF, 57425>(p, stream, sk_ws, sk_ws_bytes);  // + peeled first two K-tiles (bit 15): the stores drain under them
+            case 24657: return launch_gemm256_sched<EPI, LNF, 24657>(p, stream, sk_ws, sk_ws_bytes);  // 8273 + the seam (bit 14): the K loop's overshoot requests fetch the next tile
             case 8273: return launch_gemm256_sched<EPI, LNF, 8273>(p, stream, sk_ws, sk_ws_bytes);  // two-phase K-tile with the position-free body: the default
             case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);      // two-phase K-tile, requests guarded by position (the default of round 3)
             case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);      // four-phase K-tile (the default before the buffer-form requests)
@@ -1730,6 +1879,7 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
     // the other epilogues (plain, SwiGLU, tanh, ReLU: LLaMA prefill, the head MLPs) take the two-phase K-tile too - one variant each
     if constexpr (!LNF && (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_BIAS_TANH || EPI == EPI_RELU)) {
 #ifndef SEEDMI_SCHED_ONLY
+        if (g_gemm_sched.load() == 24657 || g_gemm_sched.load() == 57425) return launch_gemm256_sched<EPI, LNF, 24641>(p, stream, sk_ws, sk_ws_bytes);
         if (g_gemm_sched.load() == 8273) return launch_gemm256_sched<EPI, LNF, 8257>(p, stream, sk_ws, sk_ws_bytes);
         if (g_gemm_sched.load() == 81) return launch_gemm256_sched<EPI, LNF, 65>(p, stream, sk_ws, sk_ws_bytes);
 #endif
@@ -1802,7 +1952,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 16383) {      // (-1 = the default; values without a compiled variant run schedule 0)
+    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 65535) {      // (-1 = the default; values without a compiled variant run schedule 0)
         if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
         return SEEDMI_OK;

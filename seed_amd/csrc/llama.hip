@@ -362,6 +362,10 @@ struct SkinnySk {
 };
 constexpr int SK2_SLAB_FLOATS = 8 * 256 + 64;                  // 8 fragments x (64 lanes x 4) + row sums [2][16] (+ pad)
 constexpr int SK2_FLAG_WORDS = 1024;
+// word SK2_FLAG_WORDS - 1: the sticky error word; word SK2_FLAG_WORDS - 2: the tag seedmi_gemm_skinny_workspace_init wrote - a status call on a
+// workspace that was never initialised reports THAT instead of whatever the error word's bytes happen to hold
+constexpr int SK2_LIVE_WORDS = SK2_FLAG_WORDS - 2;          // hand-off flags proper (one per workgroup)
+constexpr unsigned SK2_TAG = 0x5eed514bu;
 constexpr size_t SK2_WS_BYTES = (size_t)SK2_FLAG_WORDS * 4 + (size_t)(SK2_FLAG_WORDS - 1) * SK2_SLAB_FLOATS * 4;
 
 template <int EPI>
@@ -607,7 +611,11 @@ std::atomic<int> g_skinny_sk{1};
 // r04_call5_prefill_streamk_selective.log): 107.9 / 112.0 ms without, 117.2 ms with 2, 124.9 / 127.0 ms with 1 - the hand-off (a 256 KiB
 // fp32 image written through and read back per shared tile, a pipeline refill per segment) costs more than the badly filled round wastes,
 // for the short GEMMs too.  Bit-identical logits in every mode.
+// Devtools build only since round 5: the product workspace no longer carries the 64 MiB stream-K area, and nothing checked the GEMM's sticky
+// stream-K error word on this path.
+#ifdef SEEDMI_DEVTOOLS
 std::atomic<int> g_prefill_streamk{0};
+#endif
 
 // best fill of the last round of workgroups over the row-tile counts launch_skinny_nw may pick (R = 1..3)
 bool skinny_rounds_underfilled(int M, int N) {
@@ -671,10 +679,10 @@ template <int EPI>
 int launch_skinny_sk(const SkinnyParams& p, void* ws, int mode, hipStream_t s) {
     const bool force_cut = mode == 2;
     int grid = seedmi_device_cus(seedmi_current_device());          // one 512-thread workgroup per CU (up to 182 VGPRs): every workgroup is resident
-    if (grid > SK2_FLAG_WORDS - 1) grid = SK2_FLAG_WORDS - 1;
+    if (grid > SK2_LIVE_WORDS) grid = SK2_LIVE_WORDS;
     const int tiles16 = (p.N + 15) / 16;
 #ifdef SEEDMI_DEVTOOLS
-    if (mode == 4 && 2 * grid <= SK2_FLAG_WORDS - 1) return launch_skinny_sk_r<EPI, 4, 2>(p, ws, 2 * grid, s);      // (experiment: 2 workgroups per CU)
+    if (mode == 4 && 2 * grid <= SK2_LIVE_WORDS) return launch_skinny_sk_r<EPI, 4, 2>(p, ws, 2 * grid, s);      // (experiment: 2 workgroups per CU)
 #endif
     if (!force_cut) {
         if ((tiles16 % 3) == 0 && ((tiles16 / 3) % grid) == 0) return launch_skinny_sk_r<EPI, 3>(p, ws, grid, s);
@@ -1212,11 +1220,7 @@ LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     // serves prefills and decode steps alike (LlamaEngine's) must not have a prefill's activations land on the flag words - the sticky
     // error word among them is cleared by nobody but seedmi_llama_decode_status (zeroed once by the caller after allocation)
     void* const sk_area = c.take(SK2_WS_BYTES);
-    // ... and, behind it at a fixed offset too, the stream-K workspace of the prefill's MFMA GEMMs (seedmi_gemm_bf16_ws): flag words +
-    // one fp32 accumulator image per CU.  A prefill of 8 x 649 tokens at 14B width is 21 m-tiles: o_proj / down (N = 5120) are 420 tiles
-    // = 1.64 rounds of 256 CUs, i.e. 2 rounds data-parallel; cut into equal K ranges every workgroup ends together (bit-identical results)
-    t.gsk_bytes = seedmi_gemm_workspace_bytes();
-    t.gsk = c.take(t.gsk_bytes);
+    t.gsk = nullptr; t.gsk_bytes = 0;
     t.x = (bf16_t*)c.take(M * h * 2);
     t.xn = (bf16_t*)c.take(Mp * h * 2);
     t.qkv = (bf16_t*)c.take(M * 3 * h * 2);
@@ -1233,6 +1237,13 @@ LlamaWs carve(const seedmi_llama_weights_t* w, int B, int T, void* ws) {
     if (T == 1 && M <= 32) {
         t.mega_stride = (Mp * (3 * h + h + h + F + h) * 2 + 255) / 256 * 256;
         t.mega = (bf16_t*)c.take(t.mega_stride * (size_t)w->layers);
+    }
+    // devtools only (measured slower and left out of the product library, see g_prefill_streamk): the stream-K workspace of the prefill's MFMA
+    // GEMMs (seedmi_gemm_bf16_ws: flag words + one fp32 accumulator image per CU, ~64 MiB on 256 CUs), LAST and only for prefill shapes, so
+    // that no other buffer's offset depends on the device's CU count
+    if (M > 64) {
+        t.gsk_bytes = seedmi_gemm_workspace_bytes();
+        t.gsk = c.take(t.gsk_bytes);
     }
 #endif
     t.bytes = c.off;
@@ -1304,12 +1315,14 @@ int linear(int M, int N, int K, const void* A, int lda, const void* W, const voi
         return seedmi_gemm_skinny_bf16(M, N, K, A, lda, W, K, R, ldr, epi, C, ldc, s);
     }
     // (with a workspace the persistent 256x256 kernel balances a partial last round of tiles by stream-K; NULL = data-parallel walk)
+#ifdef SEEDMI_DEVTOOLS
     if (gemm_ws && g_prefill_streamk.load(std::memory_order_relaxed) == 2) {
         const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
         const int n_cu = seedmi_device_cus(seedmi_current_device());
         const long long last = tiles % n_cu;
         if (!(tiles < 3LL * n_cu && last != 0 && 4 * last < 3LL * n_cu)) gemm_ws = nullptr;
     }
+#endif
     return seedmi_gemm_bf16_ws(M, N, K, A, lda, W, K, nullptr, R, ldr, epi, C, ldc, 0, 0, gemm_ws, gemm_ws_bytes, s);
 }
 
@@ -1520,8 +1533,8 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_splitk") && (value >= 0 && value <= 3)) { g_skinny_sk = value; return SEEDMI_OK; }
-    if (!strcmp(key, "prefill_streamk") && (value >= 0 && value <= 2)) { g_prefill_streamk = value; return SEEDMI_OK; }
 #ifdef SEEDMI_DEVTOOLS
+    if (!strcmp(key, "prefill_streamk") && (value >= 0 && value <= 2)) { g_prefill_streamk = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_splitk") && value == 4) { g_skinny_sk = value; return SEEDMI_OK; }
 #endif
     if (!strcmp(key, "decode_fused") && (value == 0 || value == 1)) { g_decode_fused = value; return SEEDMI_OK; }
@@ -1747,18 +1760,45 @@ extern "C" int seedmi_gemm_skinny_ws_status(void* workspace, size_t workspace_by
         seedmi_set_error("seedmi_gemm_skinny_ws_status: not a split-K workspace (seedmi_gemm_skinny_workspace_bytes())");
         return SEEDMI_E_SHAPE;
     }
-    unsigned word = 0;
+    unsigned words[2] = {0, 0};                       // tag, error word
     unsigned* dev = (unsigned*)workspace + (SK2_FLAG_WORDS - 1);
-    if (hipMemcpyAsync(&word, dev, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+    if (hipMemcpyAsync(words, dev - 1, 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
         seedmi_set_error("seedmi_gemm_skinny_ws_status: reading the error word failed");
         return SEEDMI_E_HIP;
     }
+    if (words[0] != SK2_TAG) {
+        seedmi_set_error("seedmi_gemm_skinny_ws_status: this workspace was never initialised (seedmi_gemm_skinny_workspace_init / "
+                         "seedmi_llama_workspace_init after allocation): its flag and error words are whatever the allocation held");
+        return SEEDMI_E_SHAPE;
+    }
+    const unsigned word = words[1];
     if (word == 0) return SEEDMI_OK;
     (void)hipMemsetAsync(dev, 0, 4, (hipStream_t)stream);
     seedmi_set_error("split-K decode GEMM: workgroup %u gave up waiting for a partner's partial tile (the grid was not fully resident, "
                      "e.g. another stream's kernel held CUs): results computed through this workspace since the last check are invalid", word - 1);
     return SEEDMI_E_HIP;
+}
+
+// Once after allocation: hand-off flags and error word zero, tag set (stream-ordered; no synchronisation)
+extern "C" int seedmi_gemm_skinny_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < SK2_WS_BYTES || ((uintptr_t)workspace & 255)) {
+        seedmi_set_error("seedmi_gemm_skinny_workspace_init: need seedmi_gemm_skinny_workspace_bytes() bytes, 256-byte aligned");
+        return SEEDMI_E_SHAPE;
+    }
+    static const unsigned tail[2] = {SK2_TAG, 0u};
+    if (hipMemsetAsync(workspace, 0, SK2_LIVE_WORDS * 4, (hipStream_t)stream) != hipSuccess ||
+        hipMemcpyAsync((unsigned*)workspace + SK2_LIVE_WORDS, tail, 8, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+        seedmi_set_error("seedmi_gemm_skinny_workspace_init: clearing the flag words failed");
+        return SEEDMI_E_HIP;
+    }
+    return SEEDMI_OK;
+}
+
+extern "C" int seedmi_llama_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    // (the split-K area is the FIRST region of every llama workspace, whatever (batch, T) it was sized for: carve())
+    if (workspace && workspace_bytes < SK2_WS_BYTES) return SEEDMI_OK;      // too small to hold decode steps' split-K area: nothing to initialise
+    return seedmi_gemm_skinny_workspace_init(workspace, workspace_bytes, stream);
 }
 
 extern "C" int seedmi_llama_decode_status(const seedmi_llama_weights_t* w, int batch, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1864,7 +1904,7 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
             return SEEDMI_E_HIP;
         }
     } else if (fused_first) {
-        CK(seedmi_embed_rows_decode(ids_i64, w->embed, h, t.x, h, t.xn, M, h, w->vocab, sk, sk ? SK2_FLAG_WORDS - 1 : 0, stream));   // (not the sticky error word)
+        CK(seedmi_embed_rows_decode(ids_i64, w->embed, h, t.x, h, t.xn, M, h, w->vocab, sk, sk ? SK2_LIVE_WORDS : 0, stream));   // (not the tag, not the sticky error word)
     } else {
         CK(seedmi_embed_rows(ids_i64, w->embed, h, t.x, h, M, h, w->vocab, stream));
     }
@@ -1880,12 +1920,17 @@ static int llama_forward_impl(const seedmi_llama_weights_t* w, const void* ids_i
     };
     // stream-K tail of the MFMA GEMMs (prefill, M > 64): its flag words are cleared once per call, so the workspace's history (another
     // shape's activations may have lived there before this area moved to the front) never matters
+#ifdef SEEDMI_DEVTOOLS
     void* const gsk = (M > 64 && g_prefill_streamk.load(std::memory_order_relaxed)) ? t.gsk : nullptr;
-    if (gsk && hipMemsetAsync(gsk, 0, 4096, (hipStream_t)stream) != hipSuccess) {
+    // (all flag words but the LAST one: that is gemm256's sticky "lost partner" word, which only a status reader may clear)
+    if (gsk && hipMemsetAsync(gsk, 0, 4096 - 4, (hipStream_t)stream) != hipSuccess) {
         seedmi_set_error("seedmi_llama_forward: clearing the stream-K flag words failed");
         return SEEDMI_E_HIP;
     }
-    if (sk && !fused_first && hipMemsetAsync(sk, 0, (SK2_FLAG_WORDS - 1) * 4, (hipStream_t)stream) != hipSuccess) {     // (the kernels leave the
+#else
+    void* const gsk = nullptr;
+#endif
+    if (sk && !fused_first && hipMemsetAsync(sk, 0, SK2_LIVE_WORDS * 4, (hipStream_t)stream) != hipSuccess) {     // (the kernels leave the
         seedmi_set_error("seedmi_llama_forward: clearing the split-K flag words failed");                       //  words zero: safety net)
         return SEEDMI_E_HIP;
     }

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEEDMI_LIB_PATH") or os.path.join(_HERE, "libseedmi.so")     # (override: A/B builds of the library)
 
-ABI_VERSION = 3            # == SEEDMI_ABI_VERSION of include/seedmi.h; load() refuses a library built from another header
+ABI_VERSION = 4            # == SEEDMI_ABI_VERSION of include/seedmi.h; load() refuses a library built from another header
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_BIAS_TANH, EPI_SWIGLU, EPI_PATCH_EMBED, EPI_RELU = range(8)
 
@@ -108,6 +108,8 @@ SIGNATURES = {
     "seedmi_gemm_skinny_norm_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "seedmi_gemm_skinny_workspace_bytes": (C.c_size_t, []),
     "seedmi_gemm_skinny_ws_status": (_i, [_vp, C.c_size_t, _vp]),
+    "seedmi_gemm_skinny_workspace_init": (_i, [_vp, C.c_size_t, _vp]),
+    "seedmi_llama_workspace_init": (_i, [_vp, C.c_size_t, _vp]),
     "seedmi_llama_decode_status": (_i, [C.POINTER(LlamaWeights), _i, _vp, C.c_size_t, _vp]),
     "seedmi_gemm_skinny_norm_ws_bf16": (_i, [_i, _i, _i, _vp, _i, _vp, C.c_float, _vp, _i, _i, _vp, _i, _i, _vp, _vp, C.c_size_t, _vp]),
     "seedmi_pack_activations_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp]),

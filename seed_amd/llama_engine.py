@@ -125,11 +125,18 @@ class LlamaEngine:
         # sized by what the library asks for THIS shape (a decode step carves regions a prefill does not: B * T alone does not order them)
         nbytes = self.lib.seedmi_llama_workspace_bytes(C.byref(self.w), B, T)
         if self._ws is None or nbytes > self._ws.numel():
-            # ZEROED once at allocation (include/seedmi.h): the split-K flag words must start at zero and the sticky error word among
-            # them is never cleared by a decode step
-            self._ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            # initialised once at allocation (include/seedmi.h: seedmi_llama_workspace_init): the split-K flag words start at zero, the
+            # sticky error word among them is never cleared by a decode step, and the status call recognises the workspace by its tag
+            self._ws = self.new_workspace(nbytes)
             self._ws_key = (B, T)
         return self._ws
+
+    def new_workspace(self, nbytes: int) -> torch.Tensor:
+        """A llama workspace as the C ABI wants it handed over: allocated, then seedmi_llama_workspace_init (stream-ordered)."""
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.seedmi_llama_workspace_init(L.ptr(ws), ws.numel(), L.stream_ptr()), "seedmi_llama_workspace_init")
+        return ws
 
     def reset(self):
         self.past_len = 0

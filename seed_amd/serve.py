@@ -186,11 +186,19 @@ class GenerateService:
             for cb in batchers.values():
                 results[id(cb)] = cb.run()
         except Exception:
-            # a decode loop failed midway: nothing of this call may stay queued in the batchers that have not run yet (or in the
-            # failed one), or the next call would decode and discard it
+            # a decode loop failed midway: nothing of this call may stay behind in the batchers that did not finish - not the requests
+            # still waiting, not the ones already prefilled into slots, not finished results run() never handed out (run() raised before
+            # swapping `done` out, or decode_status raised at its end) - or the next call would decode orphaned slots and return stale ids.
+            # Such a batcher is aborted and dropped from the cache: the next request of that sampling configuration builds a clean one.
             for i, (cb, rid) in tickets.items():
                 if id(cb) not in results and hasattr(cb, "cancel"):
                     cb.cancel(rid)
+            for cb in batchers.values():
+                if id(cb) not in results:
+                    if hasattr(cb, "abort"):
+                        cb.abort()
+                    for k in [k for k, v in self._batchers.items() if v is cb]:
+                        del self._batchers[k]
             raise
         out = []
         for i, q in enumerate(parsed):

@@ -138,7 +138,7 @@ def test_argument_validation_returns_status_codes_and_messages():
     assert l.seedmi_set_option(b"attn_vit", 5) == 0                      # the default (staggered 16-wave kernel)
     assert l.seedmi_set_option(b"attn_xcd", 0) == 0 and l.seedmi_set_option(b"attn_xcd", 2) == E_SHAPE and l.seedmi_set_option(b"attn_xcd", 1) == 0
     assert l.seedmi_set_option(b"gemm_sched", 81) == 0 and l.seedmi_set_option(b"gemm_sched", 8273) == 0
-    assert l.seedmi_set_option(b"gemm_sched", 16384) == E_SHAPE and l.seedmi_set_option(b"gemm_sched", -1) == 0
+    assert l.seedmi_set_option(b"gemm_sched", 65536) == E_SHAPE and l.seedmi_set_option(b"gemm_sched", -1) == 0
     with pytest.raises(lib.SeedmiError, match="unknown option"):
         lib.check(l.seedmi_set_option(b"gemm", 7), "seedmi_set_option")
 

@@ -69,7 +69,8 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[128, 256, (256, 0), (256, 81)], ids=["gemm128", "gemm256", "gemm256_sched0", "gemm256_sched81"])
+@pytest.fixture(params=[128, 256, (256, 0), (256, 81), (256, 8273), (256, 24657), (256, 57425)],
+                ids=["gemm128", "gemm256", "gemm256_sched0", "gemm256_sched81", "gemm256_sched8273", "gemm256_seam", "gemm256_peel"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (128x128 two-barrier and 256x256 staggered deep pipeline), the 256x256 kernel
     under its default schedule (gemm_sched 8273: two-phase K-tile, position-free body, round 4), under the round-2 schedule (0) and
@@ -818,11 +819,15 @@ def _unpack_activations(packed, rows, cols):
 def _skinny_ws(lib):
     """Zeroed workspace of the split-K decode GEMM (flag words first) + a checker: flags all zero again, error word clear."""
     nbytes = lib.seedmi_gemm_skinny_workspace_bytes()
-    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    ws = torch.full((nbytes,), 0xa5, dtype=torch.uint8, device="cuda")        # (NOT zeroed: seedmi_gemm_skinny_workspace_init must do all of it)
+    L.check(lib.seedmi_gemm_skinny_workspace_init(L.ptr(ws), ws.numel(), L.stream_ptr()), "workspace init")
 
     def check():
-        flags = ws[:4096].view(torch.int32)
+        flags = ws[:4096].view(torch.int32).clone()
+        assert int(flags[1022]) == 0x5eed514b, "the workspace tag (word 1022) was overwritten"
+        flags[1022] = 0
         assert int(flags.abs().sum()) == 0, f"split-K flag words not cleared / error word set: {flags.nonzero().flatten().tolist()[:8]}"
+        L.check(lib.seedmi_gemm_skinny_ws_status(L.ptr(ws), ws.numel(), L.stream_ptr()), "status")
     return ws, check
 
 

@@ -540,6 +540,13 @@ def test_split_k_error_word_is_sticky_and_reported():
     with pytest.raises(L.SeedmiError, match="gave up waiting"):
         eng.decode_status(B)
     eng.decode_status(B)
+    # a workspace that never saw seedmi_llama_workspace_init (here: zeroed only) is refused by the status call instead of
+    # having its error word's bytes read as a verdict
+    raw = torch.zeros_like(ws)
+    assert eng.lib.seedmi_llama_decode_status(Ct.byref(eng.w), B, L.ptr(raw), raw.numel(), L.stream_ptr()) == -1
+    assert "never initialised" in eng.lib.seedmi_last_error().decode()
+    L.check(eng.lib.seedmi_llama_workspace_init(L.ptr(raw), raw.numel(), L.stream_ptr()), "init")
+    assert eng.lib.seedmi_llama_decode_status(Ct.byref(eng.w), B, L.ptr(raw), raw.numel(), L.stream_ptr()) == 0
 
 
 def test_padded_attention_mask_warns(tmp_path):

@@ -227,3 +227,43 @@ def test_a_failing_decode_loop_leaves_nothing_queued():
     with pytest.raises(RuntimeError, match="decode loop died"):
         svc.handle_many([{'text': 'a', 'images': [], 'top_p': 0.5}, {'text': 'b', 'images': [], 'top_p': 0.9}])
     assert made[0].cancelled == [0] and made[1].cancelled == [0]
+
+
+def test_a_failing_decode_loop_aborts_and_drops_its_batcher():
+    """requests of a failed call that were already prefilled into slots (or finished but never handed out) must not survive in
+    the batcher: it is aborted and dropped from the cache, so the next call of that sampling configuration starts from a clean one."""
+    class Boom:
+        def __init__(self, fail):
+            self.fail, self.q, self.aborted = fail, [], 0
+            self.active, self.done = {}, {}
+
+        def submit(self, ids, max_new):
+            self.q.append(max_new)
+            return len(self.q) - 1
+
+        def cancel(self, rid):
+            return False                                   # (already prefilled into a slot: not cancellable)
+
+        def abort(self):
+            self.aborted += 1
+            self.active, self.done = {}, {}
+
+        def run(self):
+            if self.fail:
+                self.active = {0: {"id": 0}}               # what a loop that died midway leaves behind
+                self.done = {0: [7, 7, 7]}
+                raise RuntimeError("decode loop died")
+            return {i: [2] for i in range(len(self.q))}
+    made = []
+
+    def factory(top_p, temperature):
+        made.append(Boom(fail=len(made) == 0))
+        return made[-1]
+    svc = _service([2])
+    svc._batcher_factory = factory
+    with pytest.raises(RuntimeError, match="decode loop died"):
+        svc.handle_many([{'text': 'a', 'images': [], 'top_p': 0.5}])
+    assert made[0].aborted == 1 and not made[0].active and not made[0].done
+    assert all(cb is not made[0] for cb in svc._batchers.values())
+    out = svc.handle_many([{'text': 'a', 'images': [], 'top_p': 0.5}])      # same configuration: a fresh batcher, no stale ids
+    assert len(made) == 2 and made[1].aborted == 0 and out[0]['text'] == '' and not out[0]['error_msg']      # ([2] = EOS only)
