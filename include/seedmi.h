@@ -49,30 +49,47 @@ extern "C" {
 #define SEEDMI_ABI_VERSION 4
 
 int seedmi_version(void);
+/* The 16-bit element type this build of the library computes in: 0 = bf16 (libseedmi.so: what BASELINE.json's configs name), 1 = IEEE
+ * fp16 (libseedmi_f16.so: the reference's shipped setting, configs/tokenizer/seed_llama_tokenizer_hf.yaml:3 `fp16: True`,
+ * models/seed_llama_tokenizer.py:58-59,86-87, configs/llm/seed_llama_8b.yaml:4).  Both are built from the same sources (-DSEEDMI_F16
+ * switches the conversions, the rounding points' target type and v_mfma_f32_16x16x32_{bf16,f16}); every "bf16" in an entry point's name
+ * or comment below reads "the library's 16-bit element".  A caller picks the library by the dtype of the tensors it passes. */
+int seedmi_compute_dtype(void);
 const char* seedmi_last_error(void);
 /* 0 if the current device is a gfx950 (MI355X); SEEDMI_E_ARCH otherwise. */
 int seedmi_check_device(void);
-/* Tuning overrides: PROCESS-WIDE selections between kernels that compute the same result (relaxed atomics: reads are race-free,
- * but they are not part of the per-stream thread-safety contract - set them before concurrent use; production callers leave the
- * defaults).  Keys (value): "gemm" (0 automatic | 128 | 256), "gemm_persist" (0|1), "gemm_streamk" (0|1: stream-K tail when a
- * workspace is passed), "gemm_group_m" (1..64 m-tiles per L2 tile group, 0 = chosen by shape: the default), "gemm_min_tiles" (256x256 kernel only at or above this
- * many tiles), "tokenize_streams" (1..4 concurrent sub-batches inside seedmi_tokenize), "tokenize_streamk" (0|1: stream-K
- * tail for the tokenizer's big GEMMs, default 0), "tokenize_lnfold" (0|1: LayerNorm folded into qkv / fc1 when the weights carry
- * the folded copies, default 1), "tokenize_split_rounds" (0|1: a big GEMM whose 256x256 tiles overshoot a whole number of rounds by
- * a few m-tiles runs those rows as a second, 128x128-tiled call; pays on one stream only, default 0), "tokenize_vq_head" (0|1: the head's last Linear fused into the VQ argmin kernel, default 1),
- * "gemm_sched" (schedule of the 256x256 kernel for the ViT epilogues: -1 = default (8273: two-phase K-tile with the position-free body), 81 = the same with position-guarded requests (the round-3 default), 31 = the four-phase K-tile with counted waits and split requests, 0 = the round-2 schedule; bit-identical results),
- * "tokenize_tile_stats" (0|1: LayerNorm statistics by 256-column tile, finalized inside the consuming GEMM instead of by
- * seedmi_layernorm_stats_finalize launches; large batches only),
- * "skinny_waves" / "skinny_rows"
- * (decode GEMM; "skinny_nt" = 0, temporal weight loads, exists in the devtools build only), "skinny_splitk" (which kernel seedmi_gemm_skinny_norm_ws_bf16 runs: 0 = the one-tile-per-workgroup kernel | 1 = the split-K kernel, uncut where the shape divides into whole tiles per workgroup: the default | 2 = the split-K kernel, always cut | 3 = the split-K kernel only where the one-tile form would leave its last round of workgroups under 95 % full), "prefill_streamk" (0|1|2: stream-K tail for the prefill's MFMA GEMMs through the llama workspace - off (default, measured faster) | every GEMM | only short GEMMs with a badly filled last round; same bits either way), "decode_fused" (0|1 RoPE + append inside decode attention), "decode_attn_early" (fused decode attention: 0 = cached rows requested after the rotation | 1 = first batch of key rows requested ahead of it: the default | 2 = key and value rows; same bits), "prefill_tiled" (0|1), "attn_store_wait" (0|1: the sixteen-wave ViT kernel's wait for the next item's K / Q leaves the previous item's output stores in flight, default 1; same bits), "attn_trv" / "attn_vit"
- * (attention kernel selection; attn_vit, for the ViT's 257-token / head-dim-88 shape: 0 = generic full-row kernel | 1 = twelve-wave ViT kernel |
- * 2 = sixteen-wave ViT kernel | 3 = sixteen-wave kernel with 16-byte output stores, same bits as 1 and 2 |
- * 4 = sixteen-wave kernel with "flash" normalisation (P rounded to half BEFORE the division by the row sum): faster, but NOT
- * bit-compatible with 0-3 - it moves a rounding point of eva_vit.py:139-156 by about 0.8 bf16 ulp rms, token ids form their own equality group |
- * 5 = kernel 3 with the two halves of the workgroup one phase apart (softmax of one half next to the MFMA / LDS phases of the other),
- * wave priorities per phase and - on a full launch, i.e. from 16 images - all heads of an image on one XCD ("attn_xcd", 0|1, default 1):
- * the DEFAULT since round 4, bit-identical to 3 | 6 = kernel 4 in that form, bit-identical to 4 | 7 = 5 without the priorities (A/B)).  Timing-only ablation switches and rejected kernel variants exist only in the -DSEEDMI_DEVTOOLS
- * build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE. */
+/* Tuning overrides: PROCESS-WIDE selections between kernels / schedules (relaxed atomics: reads are race-free, but they are not part of
+ * the per-stream thread-safety contract - set them before concurrent use; production callers leave the defaults).  The product library
+ * keeps only the keys below; every option marked "=" computes bit-identical results under every value, "~" marks the three that do not.
+ * History values of the schedules, timing-only ablations, rejected kernel variants and A/B knobs (gemm_sched 81 / 31 / ..., attn_vit 4 / 6 / 7,
+ * gemm_residual_nt, gemm_prefetch_residual, tokenize_tile_stats, skinny_waves / skinny_rows / skinny_nt, decode_persistent, *_ablate ...)
+ * exist only in the -DSEEDMI_DEVTOOLS build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE.
+ *
+ *   key                    values (default first)        what it selects
+ * = gemm                   0 | 128 | 256                 tile kernel: by shape | 128x128 | persistent 256x256
+ * = gemm_sched             -1 = 8273 | 24657 | 57425 | 0 schedule of the 256x256 kernel: two-phase K-tile, position-free body | + seam (the next
+ *                                                        tile's operands requested by the K loop's last K-tiles) | + peeled first K-tiles whose
+ *                                                        waits leave the output stores in flight | the plain four-phase schedule of round 2
+ * = gemm_persist           1 | 0                         one workgroup per CU walking tiles | one workgroup per tile
+ * = gemm_streamk           1 | 0                         stream-K tail when the caller passes a workspace (seedmi_gemm_bf16_ws)
+ * = gemm_group_m           0 | 1..64                     m-tiles per L2 tile group (0: by shape)
+ * = gemm_min_tiles         160 | 1..4096                 fewer 256x256 tiles than this -> 128x128 kernel
+ * = tokenize_streams       2 | 1..4                      concurrent sub-batches inside seedmi_tokenize
+ * = tokenize_streamk       0 | 1                         stream-K tail for the tokenizer's big GEMMs
+ * = tokenize_split_rounds  0 | 1                         whole rounds of 256x256 tiles + a 128x128-tiled remainder call
+ * = tokenize_vq_head       1 | 0                         encode_task_layer's last Linear fused into the VQ argmin kernel
+ * ~ tokenize_lnfold        1 | 0                         LayerNorm folded into qkv / fc1 (one rounding) | explicit LayerNorm launches (the
+ *                                                        reference's two roundings): the documented fidelity switch of the ViT
+ * ~ skinny_splitk          1 | 0 | 2 | 3                 decode GEMM: balanced split-K where the shape asks | one tile per workgroup | always cut |
+ *                                                        cut only badly filled shapes - equal up to the order of the fp32 K summation
+ * ~ prefill_tiled          1 | 0                         LDS-tiled causal prefill attention | the row-at-a-time kernel
+ * = decode_fused           1 | 0                         RoPE + cache append inside the decode attention launch
+ * = decode_attn_early      1 | 0 | 2                     which cached rows the fused decode attention requests ahead of the rotation
+ * = attn_vit               5 | 0 | 1 | 2 | 3             ViT attention (257 tokens, head dim 88): staggered sixteen-wave | generic full-row |
+ *                                                        twelve-wave | sixteen-wave | sixteen-wave, 16-byte stores
+ * = attn_xcd               1 | 0                         all heads of an image on one XCD (attn_vit 5, full launches)
+ * = attn_store_wait        1 | 0                         attn_vit 5: the wait for the next item's K / Q leaves the output stores in flight
+ * = attn_trv               1 | 0                         generic kernel: V through ds_read_b64_tr_b16 | a transposed LDS image */
 int seedmi_set_option(const char* key, int value);
 
 /* ---- GEMM epilogues ------------------------------------------------------------------------------------------ */

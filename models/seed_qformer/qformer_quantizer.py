@@ -33,9 +33,6 @@ class _DeviceHandle:
         return self
 
 
-_warned_half = False
-
-
 def _norm_device(device):
     """torch.device('cuda') and torch.device('cuda', current) name the same device: compare with the index filled in."""
     dev = torch.device(device)
@@ -54,6 +51,7 @@ class Blip2QformerQuantizer:
         self._device = _norm_device(device) if device is not None else None
         self._engine = None
         self._out_dtype = torch.bfloat16              # dtype handed to the diffusers pipeline by get_codebook_entry
+        self._compute_dtype = torch.bfloat16          # the encode path's 16-bit element: bf16 (BASELINE.json) until .half() asks for fp16
         self._detok = None
 
     # -- reference constructor path (qformer_quantizer.py:340-375)
@@ -61,7 +59,7 @@ class Blip2QformerQuantizer:
     def from_pretrained(cls, pretrained_model_path, **kwargs):
         cfg = kwargs.pop("cfg", SEED2)
         device = kwargs.pop("device", "cuda")
-        kwargs.pop("vit_precision", None)             # qformer_quantizer.py:341: 'fp16' | 'fp32'; one compute type here (see half())
+        kwargs.pop("vit_precision", None)             # qformer_quantizer.py:341: 'fp16' | 'fp32'; the compute type is chosen by .half() / .bfloat16()
         if isinstance(pretrained_model_path, dict):
             ckpt = pretrained_model_path
         elif str(pretrained_model_path).startswith("http"):
@@ -74,23 +72,29 @@ class Blip2QformerQuantizer:
     def eval(self):
         return self
 
+    def _set_compute(self, dtype):
+        """The tokenizer engine computes in ONE 16-bit element type, chosen here: changing it drops the packed engine (rebuilt on demand)."""
+        if dtype != self._compute_dtype:
+            self._compute_dtype = dtype
+            self._engine = None
+
     def half(self):
-        """The reference runs fp16 (configs/tokenizer/seed_llama_tokenizer_hf.yaml:3, seed_llama_tokenizer.py:58-59); this
-        library has ONE compute type, bf16 with fp32 accumulation (BASELINE.json's dtype): same exponent range as fp32,
-        8 instead of 11 significand bits.  Say so once instead of silently narrowing."""
-        global _warned_half
-        if not _warned_half:
-            warnings.warn("Blip2QformerQuantizer.half(): the MI355X path computes in bfloat16 (fp32 accumulation), not "
-                          "float16; token ids can differ from an fp16 run on near-tie codes", RuntimeWarning, stacklevel=2)
-            _warned_half = True
+        """The reference's shipped setting (configs/tokenizer/seed_llama_tokenizer_hf.yaml:3 `fp16: True`, seed_llama_tokenizer.py:58-59):
+        the encode path then runs through libseedmi_f16.so - the same kernels and rounding places with IEEE fp16 as the 16-bit element
+        (round 5; until then .half() only warned and kept bf16).  The de-tokenizer front half still computes in bf16 and hands its result
+        over in fp16."""
+        self._set_compute(torch.float16)
         self._out_dtype = torch.float16               # get_codebook_entry feeds an fp16 diffusers pipeline (:309-338)
         return self
 
     def bfloat16(self):
+        self._set_compute(torch.bfloat16)
         self._out_dtype = torch.bfloat16
         return self
 
     def float(self):
+        # (there is no fp32 compute path: fp32 callers get the default bf16 engine and fp32 outputs)
+        self._set_compute(torch.bfloat16)
         self._out_dtype = torch.float32
         return self
 
@@ -109,7 +113,7 @@ class Blip2QformerQuantizer:
         if self._engine is None:
             if self._state_dict is None:
                 raise RuntimeError("Blip2QformerQuantizer has no weights (use from_pretrained or pass state_dict)")
-            self._engine = TokenizerEngine(self._state_dict, self.cfg, device=self._device)   # raises without a GPU
+            self._engine = TokenizerEngine(self._state_dict, self.cfg, device=self._device, dtype=self._compute_dtype)   # raises without a GPU
         return self._engine
 
     def get_codebook_indices(self, image):

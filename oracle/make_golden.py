@@ -84,6 +84,38 @@ def tokenizer_golden(name, cfg, batch, seed_w, seed_x, ref):
           "agree", (ids32 == ids16).float().mean().item() if have16 else None)
 
 
+def tokenizer_golden_fp16(name, cfg, batch, seed_w, seed_x, ref, ln_jitter=0.05, full=False):
+    """The reference's own modules in their SHIPPED precision: native fp16 (`fp16: True`, configs/tokenizer/seed_llama_tokenizer_hf.yaml:3;
+    model.half() / img.half(), models/seed_llama_tokenizer.py:58-59,86-87; on CPU maybe_autocast is a nullcontext, blip2.py:45, so every op
+    runs in fp16 with ln_vision's fp32 island kept).  Same weights, images and calibrated codebook as the fp32 / bf16 golden of that name
+    (the codebook is a function of the fp32 run's z), stored as tokenizer_<name>_fp16.npz next to it."""
+    torch.manual_seed(0)
+    sd = make_tokenizer_state_dict(cfg, seed=seed_w, ln_jitter=ln_jitter) if ln_jitter else make_tokenizer_state_dict(cfg, seed=seed_w)
+    image = torch.randn(batch, 3, cfg.img_size, cfg.img_size, generator=torch.Generator().manual_seed(seed_x))
+    mods = ref_shims.build_reference_tokenizer_modules(ref, cfg)
+    load_tokenizer_weights(mods, sd)
+    qt = sd["query_tokens"].clone()
+    _, taps = ref_shims.reference_get_codebook_indices(mods, qt, image)
+    cb = calibrate_codebook(taps["z"], cfg.n_embed, seed=7)
+    mods.quantize.embedding.weight.data.copy_(cb)
+    ids32, taps32 = ref_shims.reference_get_codebook_indices(mods, qt, image)
+    for m in (mods.visual_encoder, mods.Qformer, mods.quantize, mods.encode_task_layer):
+        m.half()
+    for prm in mods.ln_vision.parameters():
+        prm.data = prm.data.half().float()
+    ids16, taps16 = ref_shims.reference_get_codebook_indices(mods, qt.half(), image.half())
+    out = dict(seed_w=seed_w, seed_x=seed_x, batch=batch, ln_jitter=ln_jitter, image_sum=np.float64(image.double().sum().item()),
+               ids_fp32=ids32.numpy().astype(np.int16), ids_fp16=ids16.numpy().astype(np.int16), z_fp32=taps32["z"].numpy(),
+               z_fp16=taps16["z"].float().numpy(), qformer_out_fp16=taps16["qformer_out"].float().numpy(),
+               image_embeds_fp16_slice=taps16["image_embeds"][:, :8, :64].float().numpy(),
+               image_embeds_fp32_slice=taps32["image_embeds"][:, :8, :64].numpy())
+    if not full:
+        out["codebook"] = cb.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, f"tokenizer_{name}_fp16.npz"), **out)
+    print(name, "fp16: ids[0,:8] fp32", ids32[0, :8].tolist(), "fp16", ids16[0, :8].tolist(), "reference fp16 vs fp32 id agreement",
+          (ids32 == ids16).float().mean().item(), "z rel", ((taps16["z"].float() - taps32["z"]).norm() / taps32["z"].norm()).item())
+
+
 def tokenizer_golden_full(ref, batch=16, seed_w=0, seed_x=1234):
     """The full SEED-2 tokenizer (EVA-ViT-g/14, 39 blocks + 12-layer Q-Former + 8192 x 32 codebook) through the reference's own
     modules, fp32 and native bf16, on ``batch`` images: pins the oracle AND the HIP path at the real size.
@@ -201,6 +233,9 @@ def main():
     detok_golden("tiny", C.TINY, 3, 11, 5, ref)
     detok_golden("full", C.SEED2, 2, 12, 6, ref)
     tokenizer_golden_full(ref)
+    tokenizer_golden_fp16("tiny", C.TINY, 3, 0, 1234, ref)
+    tokenizer_golden_fp16("mid", C.MID, 2, 1, 4321, ref)
+    tokenizer_golden_fp16("full", C.SEED2, 16, 0, 1234, ref, ln_jitter=0.0, full=True)
 
 
 if __name__ == "__main__":

@@ -33,14 +33,18 @@ import torch.nn.functional as F
 
 
 class Prec:
+    """fp32 = ground truth; "bf16" / "fp16" = the same choreography (where the reference materialises a half tensor)
+    with that element type - bf16 is what BASELINE.json's configs name, fp16 what the reference ships (seed_llama_tokenizer_hf.yaml:3)."""
+
     def __init__(self, mode: str):
-        assert mode in ("fp32", "bf16")
+        assert mode in ("fp32", "bf16", "fp16")
         self.mode = mode
-        self.half = mode == "bf16"
+        self.half = mode != "fp32"
+        self.dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[mode]
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
         """Round to the model's half type (identity in fp32 mode)."""
-        return x.bfloat16().float() if self.half else x
+        return x.to(self.dtype).float() if self.half else x
 
 
 def _w(sd, name, prec: Prec):
@@ -218,7 +222,12 @@ def vq_distances_fixed_order(z: np.ndarray, e: np.ndarray, half: bool) -> np.nda
     """
     z = np.ascontiguousarray(z, dtype=np.float32)
     e = np.ascontiguousarray(e, dtype=np.float32)
-    rnd = _bf16_round_np if half else (lambda a: a)
+    # half: False (fp32) | True or "bf16" | "fp16" (numpy's float16 conversion rounds to nearest even, subnormals kept: what
+    # torch's .half() and v_cvt_f16_f32 do)
+    if half == "fp16":
+        rnd = lambda a: np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)      # noqa: E731
+    else:
+        rnd = _bf16_round_np if half else (lambda a: a)
     D = z.shape[1]
     zz = np.zeros(z.shape[0], np.float32)
     ee = np.zeros(e.shape[0], np.float32)
@@ -242,7 +251,7 @@ def vq_argmin(z: torch.Tensor, codebook: torch.Tensor, prec: Prec, return_gap: b
     gaps = np.empty(zf.shape[0], np.float32)
     step = 1024
     for s0 in range(0, zf.shape[0], step):
-        d = vq_distances_fixed_order(zf[s0:s0 + step], ef, prec.half)
+        d = vq_distances_fixed_order(zf[s0:s0 + step], ef, prec.mode if prec.half else False)
         ids[s0:s0 + step] = np.argmin(d, axis=1)                      # first minimal index
         if return_gap:
             part = np.partition(d, 1, axis=1)

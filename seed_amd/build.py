@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libseedmi.so")
 LIB_DEV = os.path.join(HERE, "libseedmi_dev.so")
+LIB_F16 = os.path.join(HERE, "libseedmi_f16.so")          # the same sources with -DSEEDMI_F16: IEEE fp16 as the 16-bit element (csrc/common.h)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["capi.hip", "gemm_bf16.hip", "attn_fullrow.hip", "attn_vit.hip", "norm_misc.hip", "vq_argmin.hip", "tokenizer.hip", "detokenizer.hip", "preprocess.hip", "sample.hip", "llama.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
@@ -61,13 +62,15 @@ def build_variant(name: str, defines, verbose: bool = True) -> str:
     return lib
 
 
-def build(force: bool = False, verbose: bool = True, devtools: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, devtools: bool = False, f16: bool = False) -> str:
     """devtools=True builds libseedmi_dev.so with -DSEEDMI_DEVTOOLS: the product library plus timing-only ablation switches,
     rejected kernel variants and micro-benchmarks that tools/ scripts use (SEEDMI_LIB_PATH selects it); never loaded by the
-    engines, tests or bench.py."""
-    objdir = OBJ + ("_dev" if devtools else "")
-    lib = LIB_DEV if devtools else LIB
-    extra = ("-DSEEDMI_DEVTOOLS",) if devtools else ()
+    engines, tests or bench.py.  f16=True builds libseedmi_f16.so (-DSEEDMI_F16): the product library with IEEE fp16 as its
+    16-bit element - what the engines load for torch.float16 weights."""
+    assert not (devtools and f16)
+    objdir = OBJ + ("_dev" if devtools else "_f16" if f16 else "")
+    lib = LIB_DEV if devtools else LIB_F16 if f16 else LIB
+    extra = ("-DSEEDMI_DEVTOOLS",) if devtools else ("-DSEEDMI_F16",) if f16 else ()
     os.makedirs(objdir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         results = list(ex.map(lambda s: _compile(s, force, objdir, extra), SOURCES))
@@ -90,4 +93,4 @@ if __name__ == "__main__":
         i = sys.argv.index("--variant")
         build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")])
     else:
-        build(force="--force" in sys.argv, devtools="--devtools" in sys.argv)
+        build(force="--force" in sys.argv, devtools="--devtools" in sys.argv, f16="--f16" in sys.argv)

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(Ksm + (16 * t + li) * KPITCH + 32 * ks + 8 * g);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+                s[t] = seedmi_mfma_16x16x32(kf, qf[ks], s[t]);
             }
             // keep the scheduler from hoisting every LDS read of the unrolled tile loop (register blow-up)
             if (t & 1) __builtin_amdgcn_sched_barrier(0);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void attn_fullrow_kernel(AttnParams p) {
                     hi = *(const uint2*)(vp + 16);
                 }
                 const uint4 vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[n], 0, 0, 0);
+                o[n] = seedmi_mfma_16x16x32(__builtin_bit_cast(bf16x8, vw), pf, o[n]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -229,7 +229,14 @@ int launch_attn(const AttnParams& p, int batch, hipStream_t stream) {
 
 int seedmi_attn_set_option(const char* key, int value) {
     if (!strcmp(key, "attn_trv") && (value == 0 || value == 1)) { g_attn_trv = value; return SEEDMI_OK; }
+    // product values: 0 generic | 1 twelve-wave | 2 / 3 sixteen-wave (8- / 16-byte output stores) | 5 staggered sixteen-wave (default); all five give
+    // the same bits on rows 0..255 (row 256's side path: to 1 ulp).  4 / 6 ("flash" normalisation: moves a rounding point) and 7 (5 without wave
+    // priorities) are measurement arms: devtools build only
+#ifdef SEEDMI_DEVTOOLS
     if (!strcmp(key, "attn_vit") && value >= 0 && value <= 7) return seedmi_attn_vit_set(value);
+#else
+    if (!strcmp(key, "attn_vit") && ((value >= 0 && value <= 3) || value == 5)) return seedmi_attn_vit_set(value);
+#endif
     if (!strcmp(key, "attn_store_wait") && (value == 0 || value == 1)) return seedmi_attn_vit_store_wait(value);
     if (!strcmp(key, "attn_xcd") && (value == 0 || value == 1)) return seedmi_attn_vit_xcd(value);
     return SEEDMI_E_SHAPE;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
                         s[2 * grp + u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int ks = 0; ks < 3; ++ks)
-                            s[2 * grp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[3 * u + ks], qf[ks], s[2 * grp + u], 0, 0, 0);
+                            s[2 * grp + u] = seedmi_mfma_16x16x32(f[3 * u + ks], qf[ks], s[2 * grp + u]);
                     }
                 };
                 ldk(fk0, 0);
@@ -269,11 +269,11 @@ __global__ __launch_bounds__(64 * VWAVES) void attn_vit_kernel(VitAttnParams p) 
                     if (kk & 1) {
                         if (kk + 1 < VKK) ldv(fv0, kk + 1);
 #pragma unroll
-                        for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pf[t][kk], o[nn], 0, 0, 0);
+                        for (int nn = 0; nn < VHT; ++nn) o[nn] = seedmi_mfma_16x16x32(fv1[nn], pf[t][kk], o[nn]);
                     } else {
                         if (kk + 1 < VKK) ldv(fv1, kk + 1);
 #pragma unroll
-                        for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pf[t][kk], o[nn], 0, 0, 0);
+                        for (int nn = 0; nn < VHT; ++nn) o[nn] = seedmi_mfma_16x16x32(fv0[nn], pf[t][kk], o[nn]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                 }
                 s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kt & 1][ks], qf[ks], s[kt], 0, 0, 0);
+                for (int ks = 0; ks < 3; ++ks) s[kt] = seedmi_mfma_16x16x32(fk[kt & 1][ks], qf[ks], s[kt]);
                 __builtin_amdgcn_sched_barrier(0);         // (keeps the fragment reads one tile ahead, not ten: 128 registers per wave)
             }
             V16STAMP(2);
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                 }
                 f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], fk[kt & 1][ks], a, 0, 0, 0);
+                for (int ks = 0; ks < 3; ++ks) a = seedmi_mfma_16x16x32(qf[ks], fk[kt & 1][ks], a);
                 float v = a[0];
                 if (ROUND_S) v = rbf(v);
                 if (kt == VNT - 1) v = (li == 0) ? v : -INFINITY;   // keys 257..271 do not exist
@@ -652,11 +652,11 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                 if (kk & 1) {
                     if (kk + 1 < VKK) ldv(fv0, kk + 1);
 #pragma unroll
-                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pf[kk], o[nn], 0, 0, 0);
+                    for (int nn = 0; nn < VHT; ++nn) o[nn] = seedmi_mfma_16x16x32(fv1[nn], pf[kk], o[nn]);
                 } else {
                     if (kk + 1 < VKK) ldv(fv1, kk + 1);
 #pragma unroll
-                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pf[kk], o[nn], 0, 0, 0);
+                    for (int nn = 0; nn < VHT; ++nn) o[nn] = seedmi_mfma_16x16x32(fv0[nn], pf[kk], o[nn]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -682,11 +682,11 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                 if (kk & 1) {
                     if (kk + 1 < VKK) ldv(fv0, kk + 1);
 #pragma unroll
-                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pr, o[nn], 0, 0, 0);
+                    for (int nn = 0; nn < VHT; ++nn) o[nn] = seedmi_mfma_16x16x32(fv1[nn], pr, o[nn]);
                 } else {
                     if (kk + 1 < VKK) ldv(fv1, kk + 1);
 #pragma unroll
-                    for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pr, o[nn], 0, 0, 0);
+                    for (int nn = 0; nn < VHT; ++nn) o[nn] = seedmi_mfma_16x16x32(fv0[nn], pr, o[nn]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
             }
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kt % (DEPTH + 1)][ks], qf[ks], s[kt], 0, 0, 0);
+            for (int ks = 0; ks < 3; ++ks) s[kt] = seedmi_mfma_16x16x32(fk[kt % (DEPTH + 1)][ks], qf[ks], s[kt]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
             }
             f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], fk[kt & 1][ks], a, 0, 0, 0);
+            for (int ks = 0; ks < 3; ++ks) a = seedmi_mfma_16x16x32(qf[ks], fk[kt & 1][ks], a);
             float v = rbf(a[0]);
             if (kt == VNT - 1) v = (li == 0) ? v : -INFINITY;   // keys 257..271 do not exist
             t[kt] = v;
@@ -1070,11 +1070,11 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
             if (kk & 1) {
                 if (kk + 1 < VKK) ldv(fv0, kk + 1);
 #pragma unroll
-                for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[nn], pr, o[nn], 0, 0, 0);
+                for (int nn = 0; nn < VHT; ++nn) o[nn] = seedmi_mfma_16x16x32(fv1[nn], pr, o[nn]);
             } else {
                 if (kk + 1 < VKK) ldv(fv1, kk + 1);
 #pragma unroll
-                for (int nn = 0; nn < VHT; ++nn) o[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[nn], pr, o[nn], 0, 0, 0);
+                for (int nn = 0; nn < VHT; ++nn) o[nn] = seedmi_mfma_16x16x32(fv0[nn], pr, o[nn]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
             const bf16x8 fv = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
             const uint2 plo = *(const uint2*)(prow + 32 * kk), phi = *(const uint2*)(prow + 32 * kk + 16);
             const bf16x8 pr = __builtin_bit_cast(bf16x8, make_uint4(plo.x, plo.y, phi.x, phi.y));
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, pr, o, 0, 0, 0);
+            o = seedmi_mfma_16x16x32(fv, pr, o);
         }
         const int c0 = 16 * nn + 4 * g;                       // O^T rows 16 nn + 4 g + r of column li: only li == 0 (row 256) exists
         if (li == 0 && c0 + 4 <= VHD) {

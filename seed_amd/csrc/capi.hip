@@ -40,6 +40,14 @@ int seedmi_device_cus(int dev) {
 }
 
 extern "C" int seedmi_version(void) { return SEEDMI_ABI_VERSION; }
+// 0 = bf16 (libseedmi.so), 1 = IEEE fp16 (libseedmi_f16.so, built from the same sources with -DSEEDMI_F16)
+extern "C" int seedmi_compute_dtype(void) {
+#ifdef SEEDMI_F16
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" const char* seedmi_last_error(void) { return g_err; }
 
 extern "C" int seedmi_check_device(void) {

@@ -3,14 +3,40 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;                                            // storage type of bf16 tensors
+// The library is compiled once per 16-bit element type: bf16 (libseedmi.so, the default and what BASELINE.json's configs ask for) and
+// IEEE fp16 (-DSEEDMI_F16 -> libseedmi_f16.so: the compute type the reference ships with, configs/tokenizer/seed_llama_tokenizer_hf.yaml:3,
+// seed_llama_tokenizer.py:58-59,86-87).  Every conversion and every rounding point goes through the helpers below and every contraction
+// through seedmi_mfma_16x16x32, so the two builds differ in nothing else: same kernels, same fp32 islands, same rounding PLACES
+// (SURVEY Appendix A), v_mfma_f32_16x16x32_f16 instead of _bf16 at the same rate.  The historic names (bf16_t, *_bf16 entry points,
+// f2bf / rbf / lo_bf ...) mean "the library's 16-bit element" in both builds.
+typedef uint16_t bf16_t;                                            // storage type of 16-bit tensors
 typedef __attribute__((ext_vector_type(8))) short bf16x8;           // one MFMA A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;            // one 16x16 MFMA accumulator
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 hw_f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 hw_f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 hw_bf16x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define SEEDMI_DEVINL __device__ __forceinline__
 
+#ifdef SEEDMI_F16
+#define SEEDMI_ELEM_NAME "fp16"
+SEEDMI_DEVINL float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// round-to-nearest-even fp32 -> fp16 (v_cvt_f16_f32; values beyond 65504 become inf, as in the reference's fp16 tensors)
+SEEDMI_DEVINL bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+SEEDMI_DEVINL uint32_t pack2bf(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    hw_f16x2 r = __builtin_convertvector(v, hw_f16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+SEEDMI_DEVINL float lo_bf(uint32_t u) { return (float)__builtin_bit_cast(hw_f16x2, u)[0]; }
+SEEDMI_DEVINL float hi_bf(uint32_t u) { return (float)__builtin_bit_cast(hw_f16x2, u)[1]; }
+SEEDMI_DEVINL f32x4 seedmi_mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hw_f16x8, a), __builtin_bit_cast(hw_f16x8, b), c, 0, 0, 0);
+}
+#else
+#define SEEDMI_ELEM_NAME "bf16"
 SEEDMI_DEVINL float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even fp32 -> bf16 (lowers to v_cvt_pk_bf16_f32 on gfx950)
@@ -23,11 +49,12 @@ SEEDMI_DEVINL uint32_t pack2bf(float lo, float hi) {
     hw_bf16x2 r = __builtin_convertvector(v, hw_bf16x2);
     return __builtin_bit_cast(uint32_t, r);
 }
-// value rounded to bf16 and widened again: the point where the reference materialises a half tensor
-SEEDMI_DEVINL float rbf(float f) { return bf2f(f2bf(f)); }
-
 SEEDMI_DEVINL float lo_bf(uint32_t u) { return __uint_as_float(u << 16); }
 SEEDMI_DEVINL float hi_bf(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+SEEDMI_DEVINL f32x4 seedmi_mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#endif
+// value rounded to the 16-bit element and widened again: the point where the reference materialises a half tensor
+SEEDMI_DEVINL float rbf(float f) { return bf2f(f2bf(f)); }
 
 // Exact-erf GELU (nn.GELU(), ACT2FN['gelu']).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-level)
 // evaluated on |z| so that 1+erf(z) for z < 0 is formed without cancellation: ~14 VALU + v_exp + v_rcp instead of the

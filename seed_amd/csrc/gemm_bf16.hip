@@ -123,6 +123,13 @@ SEEDMI_DEVINL void glds16_buf(const __amdgpu_buffer_rsrc_t rsrc, uint32_t lane_b
 // ds_read_u16 instead of ~20 VALU + v_rcp + v_exp — the erf epilogue was ~30 % of an ideal fc1 tile's MFMA time; the table is what
 // torch returns for each input, so the activation is bit-identical to the reference's.  Values outside the table's range (tiny:
 // 0.5x; huge: relu(x)) are rare: a wave-uniform branch sends such rows through the polynomial form.
+// (fp16 build: fp16 has 1024 mantissa steps per binade - the same range would be a 40 KB table; there the activation is the arithmetic
+//  gelu_erf of common.h on the half fc1 output, |abs err| <= 1.5e-7 against fp16's 2^-11 relative resolution)
+#ifdef SEEDMI_F16
+constexpr bool GELU_BY_TABLE = false;
+#else
+constexpr bool GELU_BY_TABLE = true;
+#endif
 constexpr int GELU_E_MIN = 111, GELU_N = 2560, GELU_LUT_BYTES = 2 * GELU_N * 2;
 __device__ const uint16_t g_gelu_lut[2 * GELU_N] = {
 #include "gelu_lut.inc"
@@ -304,7 +311,7 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
         int out_row = m;
         uint32_t pk[8];                                                    // packed result words (table path only)
         bool packed = false;
-        if (EPI == EPI_BIAS_GELU && lut) {                                 // GELU of the half fc1 output, by table
+        if (EPI == EPI_BIAS_GELU && lut && GELU_BY_TABLE) {                // GELU of the half fc1 output, by table
             bool bad = false;
             uint32_t hw[8];
 #pragma unroll
@@ -585,7 +592,10 @@ SEEDMI_DEVINL void gemm_epilogue_fold8(const GemmParams& p, f32x4 (&acc)[8][4], 
         uint32_t pk[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) pk[i] = pack2bf(acc[mi][i >> 1][2 * (i & 1)], acc[mi][i >> 1][2 * (i & 1) + 1]);
-        if (EPI == EPI_BIAS_GELU) {                                   // GELU of the half fc1 output, by table (see gemm_epilogue)
+        if (EPI == EPI_BIAS_GELU && !GELU_BY_TABLE) {                 // fp16 build: arithmetic GELU of the half fc1 output
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pk[i] = pack2bf(gelu_erf(lo_bf(pk[i])), gelu_erf(hi_bf(pk[i])));
+        } else if (EPI == EPI_BIAS_GELU) {                            // GELU of the half fc1 output, by table (see gemm_epilogue)
             bool bad = false;
             uint32_t hw[8];
 #pragma unroll
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (EPI == EPI_BIAS_GELU) load_gelu_lut(smem + 2 * STAGE_BYTES, tid, 256);     // (the K loop's barriers order it before the epilogue)
+    if (EPI == EPI_BIAS_GELU && GELU_BY_TABLE) load_gelu_lut(smem + 2 * STAGE_BYTES, tid, 256);     // (the K loop's barriers order it before the epilogue)
     const char* lut = (EPI == EPI_BIAS_GELU) ? smem + 2 * STAGE_BYTES : nullptr;
     const int nk = p.K / BK;
     auto stage = [&](int s, int kt) {
@@ -727,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = seedmi_mfma_16x16x32(w[ni], a[mi], acc[mi][ni]);
         }
         __syncthreads();
     }
@@ -952,7 +962,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     int fold_par = 0;                                               // operand set the NEXT prologue fills
     const int n_seg = build_segments<SEAM>(p, nk, segs, tid);
     if (n_seg == 0) return;                                            // uniform for the whole workgroup
-    if (EPI == EPI_BIAS_GELU) load_gelu_lut(smem + 2 * KT_BYTES, tid, 512);   // activation table behind the operand ring
+    if (EPI == EPI_BIAS_GELU && GELU_BY_TABLE) load_gelu_lut(smem + 2 * KT_BYTES, tid, 512);   // activation table behind the operand ring
     __syncthreads();
     const char* lut = (EPI == EPI_BIAS_GELU) ? smem + 2 * KT_BYTES : nullptr;
     if (STATIC_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);      // (wave is a readfirstlane value: a scalar branch around one s_setprio)
@@ -1239,7 +1249,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = seedmi_mfma_16x16x32(fx[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni]);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
         if (stamp) GSTAMP(2);
@@ -1263,7 +1273,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
+                    acc[mi][2 + ni] = seedmi_mfma_16x16x32(fy[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni]);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
         if (stamp) GSTAMP(6);
@@ -1293,7 +1303,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
+                    acc[4 + mi][2 + ni] = seedmi_mfma_16x16x32(fy[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni]);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
@@ -1334,7 +1344,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
+                    acc[4 + mi][ni] = seedmi_mfma_16x16x32(fx[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni]);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         SEEDMI_SCHED_FENCE();
@@ -1425,10 +1435,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = seedmi_mfma_16x16x32(fw0[2 * ks + ni], fa[4 * ks + mi], acc[mi][ni]);
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni], 0, 0, 0);
+                    acc[mi][2 + ni] = seedmi_mfma_16x16x32(fw1[2 * ks + ni], fa[4 * ks + mi], acc[mi][2 + ni]);
             }
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
@@ -1459,10 +1469,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni], 0, 0, 0);
+                    acc[4 + mi][ni] = seedmi_mfma_16x16x32(fw0[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][ni]);
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni], 0, 0, 0);
+                    acc[4 + mi][2 + ni] = seedmi_mfma_16x16x32(fw1[2 * ks + ni], fa[4 * ks + mi], acc[4 + mi][2 + ni]);
             }
         SEEDMI_SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
@@ -1857,9 +1867,9 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
             case 57425: return launch_gemm256_sched<EPI, LNF, 57425>(p, stream, sk_ws, sk_ws_bytes);  // + peeled first two K-tiles (bit 15): the stores drain under them
             case 24657: return launch_gemm256_sched<EPI, LNF, 24657>(p, stream, sk_ws, sk_ws_bytes);  // 8273 + the seam (bit 14): the K loop's overshoot requests fetch the next tile
             case 8273: return launch_gemm256_sched<EPI, LNF, 8273>(p, stream, sk_ws, sk_ws_bytes);  // two-phase K-tile with the position-free body: the default
+#ifdef SEEDMI_DEVTOOLS                                 // the schedule's history and measured steps (tools/gemm_sched_ab.py): devtools build only
             case 81: return launch_gemm256_sched<EPI, LNF, 81>(p, stream, sk_ws, sk_ws_bytes);      // two-phase K-tile, requests guarded by position (the default of round 3)
             case 31: return launch_gemm256_sched<EPI, LNF, 31>(p, stream, sk_ws, sk_ws_bytes);      // four-phase K-tile (the default before the buffer-form requests)
-#ifdef SEEDMI_DEVTOOLS                                 // measured steps (tools/gemm_sched_ab.py)
             case 7: return launch_gemm256_sched<EPI, LNF, 7>(p, stream, sk_ws, sk_ws_bytes);
             case 15: return launch_gemm256_sched<EPI, LNF, 15>(p, stream, sk_ws, sk_ws_bytes);
             case 63: return launch_gemm256_sched<EPI, LNF, 63>(p, stream, sk_ws, sk_ws_bytes);
@@ -1881,7 +1891,9 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
 #ifndef SEEDMI_SCHED_ONLY
         if (g_gemm_sched.load() == 24657 || g_gemm_sched.load() == 57425) return launch_gemm256_sched<EPI, LNF, 24641>(p, stream, sk_ws, sk_ws_bytes);
         if (g_gemm_sched.load() == 8273) return launch_gemm256_sched<EPI, LNF, 8257>(p, stream, sk_ws, sk_ws_bytes);
+#ifdef SEEDMI_DEVTOOLS
         if (g_gemm_sched.load() == 81) return launch_gemm256_sched<EPI, LNF, 65>(p, stream, sk_ws, sk_ws_bytes);
+#endif
 #endif
     }
     return launch_gemm256_sched<EPI, LNF, 0>(p, stream, sk_ws, sk_ws_bytes);
@@ -1952,7 +1964,12 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_variant = value;
         return SEEDMI_OK;
     }
-    if (key && !strcmp(key, "gemm_sched") && value >= -1 && value <= 65535) {      // (-1 = the default; values without a compiled variant run schedule 0)
+#ifdef SEEDMI_DEVTOOLS
+    const bool sched_ok = value >= -1 && value <= 65535;                           // (values without a compiled variant run schedule 0)
+#else
+    const bool sched_ok = value == -1 || value == 0 || value == 8273 || value == 24657 || value == 57425;
+#endif
+    if (key && !strcmp(key, "gemm_sched") && sched_ok) {                            // (-1 = the default)
         if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
         return SEEDMI_OK;
@@ -1979,6 +1996,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_streamk = value;
         return SEEDMI_OK;
     }
+#ifdef SEEDMI_DEVTOOLS
     if (key && !strcmp(key, "gemm_prefetch_residual") && (value == 0 || value == 1)) {
         g_gemm_prefetch_r = value;
         return SEEDMI_OK;
@@ -1987,12 +2005,15 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_residual_nt = value;
         return SEEDMI_OK;
     }
+    // (statistics by tile associate the row sums differently - other bits: reachable through seedmi_gemm_bf16_ext's own arguments, the
+    //  tokenizer-wide switch is a measurement arm)
+    if (key && !strcmp(key, "tokenize_tile_stats") && seedmi_tokenizer_set_tilestats(value) == SEEDMI_OK) return SEEDMI_OK;
+#endif
     if (key && !strcmp(key, "tokenize_streams") && seedmi_tokenizer_set_streams(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_streamk") && seedmi_tokenizer_set_streamk(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_lnfold") && seedmi_tokenizer_set_lnfold(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_split_rounds") && seedmi_tokenizer_set_split(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && !strcmp(key, "tokenize_vq_head") && seedmi_tokenizer_set_vqhead(value) == SEEDMI_OK) return SEEDMI_OK;
-    if (key && !strcmp(key, "tokenize_tile_stats") && seedmi_tokenizer_set_tilestats(value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_llama_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     if (key && seedmi_attn_set_option(key, value) == SEEDMI_OK) return SEEDMI_OK;
     seedmi_set_error("seedmi_set_option: unknown option/value %s=%d", key ? key : "(null)", value);

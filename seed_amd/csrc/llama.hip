@@ -185,7 +185,7 @@ SEEDMI_DEVINL void skinny_tile(const SkinnyParams& p, const int bidx) {
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
-                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][r], af[u][t], acc[r][t], 0, 0, 0);
+                        acc[r][t] = seedmi_mfma_16x16x32(wf[u][r], af[u][t], acc[r][t]);
                 if (do_norm) {
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512, WGS == 2 ? 4 : 1) void gemm_skinny_sk_kernel(c
                         for (int r = 0; r < R; ++r)
 #pragma unroll
                             for (int t = 0; t < MT; ++t)
-                                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u2][r], af[u2][t], acc[r][t], 0, 0, 0);
+                                acc[r][t] = seedmi_mfma_16x16x32(wf[u2][r], af[u2][t], acc[r][t]);
                         if (do_norm) {
 #pragma unroll
                             for (int t = 0; t < MT; ++t) {
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 kf = *(const bf16x8*)(kb + (size_t)krow * DEC_HD + 32 * ks + 8 * g);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);
+            s = seedmi_mfma_16x16x32(kf, qf[ks], s);
         }
         float tm = -INFINITY;
 #pragma unroll
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(kb + (size_t)krow * DEC_HD + 32 * ks + 8 * g);
-                s[half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[half], 0, 0, 0);
+                s[half] = seedmi_mfma_16x16x32(kf, qf[ks], s[half]);
             }
         }
         float pv[8];
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
             const uint2 lo = *(const uint2*)vp;
             const uint2 hi = *(const uint2*)(vp + 16);
             const uint4 vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[n], 0, 0, 0);
+            o[n] = seedmi_mfma_16x16x32(__builtin_bit_cast(bf16x8, vw), pf, o[n]);
         }
     }
     if (qrow < T) {
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tiled_kernel(const bf16_t
         for (int u = 0; u < 2; ++u) {
             s[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[u][ks], s[u], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) s[u] = seedmi_mfma_16x16x32(kf[ks], qf[u][ks], s[u]);
         }
     };
 
@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tiled_kernel(const bf16_t
                 const uint2 lo = __builtin_bit_cast(uint2, a), hi = __builtin_bit_cast(uint2, cc);
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
-                for (int u = 0; u < 2; ++u) o[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kk], o[u][n], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) o[u][n] = seedmi_mfma_16x16x32(vf, pf[u][kk], o[u][n]);
             }
         }
     }
@@ -1526,12 +1526,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tiled_kernel(const bf16_t
 
 int seedmi_llama_set_option(const char* key, int value) {
 #ifdef SEEDMI_DEVTOOLS
+    // A/B knobs of the decode GEMM (workgroup shape, temporal weight loads): tools only
     if (!strcmp(key, "skinny_nt") && (value == 0 || value == 1)) { g_skinny_nt = value; return SEEDMI_OK; }
-#else
-    if (!strcmp(key, "skinny_nt") && value == 1) return SEEDMI_OK;                     // (0 = temporal loads: devtools build only)
-#endif
     if (!strcmp(key, "skinny_waves") && (value == 0 || value == 4 || value == 8)) { g_skinny_nw = value; return SEEDMI_OK; }
     if (!strcmp(key, "skinny_rows") && (value >= 0 && value <= 3)) { g_skinny_r = value; return SEEDMI_OK; }
+    if (!strcmp(key, "decode_ablate_norm") && (value == 0 || value == 1)) { g_ablate_norm = value; return SEEDMI_OK; }
+#endif
     if (!strcmp(key, "skinny_splitk") && (value >= 0 && value <= 3)) { g_skinny_sk = value; return SEEDMI_OK; }
 #ifdef SEEDMI_DEVTOOLS
     if (!strcmp(key, "prefill_streamk") && (value >= 0 && value <= 2)) { g_prefill_streamk = value; return SEEDMI_OK; }
@@ -1544,7 +1544,6 @@ int seedmi_llama_set_option(const char* key, int value) {
     if (!strcmp(key, "skinny_ablate") && (value >= 0 && value <= 7)) { g_skinny_abl = value; return SEEDMI_OK; }
 #endif
     if (!strcmp(key, "prefill_tiled") && (value == 0 || value == 1)) { g_prefill_tiled = value; return SEEDMI_OK; }
-    if (!strcmp(key, "decode_ablate_norm") && (value == 0 || value == 1)) { g_ablate_norm = value; return SEEDMI_OK; }
     return SEEDMI_E_SHAPE;
 }
 

@@ -75,6 +75,7 @@ class LlamaWeights(C.Structure):
 # name -> (restype, argtypes); must list every symbol include/seedmi.h declares (tests check the export table)
 SIGNATURES = {
     "seedmi_version": (_i, []),
+    "seedmi_compute_dtype": (_i, []),
     "seedmi_last_error": (C.c_char_p, []),
     "seedmi_check_device": (_i, []),
     "seedmi_set_option": (_i, [C.c_char_p, _i]),
@@ -139,13 +140,41 @@ class SeedmiError(RuntimeError):
 
 
 _lib = None
+_lib_f16 = None
+LIB_PATH_F16 = os.environ.get("SEEDMI_LIB_PATH_F16", os.path.join(_HERE, "libseedmi_f16.so"))
 
 
-def load():
-    """Load libseedmi.so and bind every declared symbol.  Raises if the library is not built."""
-    global _lib
-    if _lib is not None:
+def _is_f16(dtype) -> bool:
+    """torch.float16 / "fp16" / "float16" select the fp16 build; None, torch.bfloat16, "bf16" the default one."""
+    if dtype is None:
+        return False
+    name = str(dtype).replace("torch.", "")
+    if name in ("float16", "fp16", "half"):
+        return True
+    if name in ("bfloat16", "bf16"):
+        return False
+    raise SeedmiError(f"no build of the library computes in {dtype}: the 16-bit element is bfloat16 (libseedmi.so) or float16 (libseedmi_f16.so)")
+
+
+def load(dtype=None):
+    """Load the library that computes in ``dtype`` (default / torch.bfloat16: libseedmi.so; torch.float16: libseedmi_f16.so, the same
+    sources built with -DSEEDMI_F16) and bind every declared symbol.  Raises if the library is not built."""
+    global _lib, _lib_f16
+    f16 = _is_f16(dtype)
+    if f16 and _lib_f16 is not None:
+        return _lib_f16
+    if not f16 and _lib is not None:
         return _lib
+    path = LIB_PATH_F16 if f16 else LIB_PATH
+    lib = _load_path(path, 1 if f16 else 0)
+    if f16:
+        _lib_f16 = lib
+    else:
+        _lib = lib
+    return lib
+
+
+def _load_path(LIB_PATH, want_dtype):
     if not os.path.exists(LIB_PATH):
         raise SeedmiError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU / PyTorch fallback for the hot path)")
@@ -158,7 +187,8 @@ def load():
     if got != ABI_VERSION:
         raise SeedmiError(f"{LIB_PATH} reports C-ABI version {got}, this binding was written for {ABI_VERSION} (include/seedmi.h): "
                           "rebuild the library (`python -m seed_amd.build --force`); argument lists and struct layouts differ between versions")
-    _lib = lib
+    if lib.seedmi_compute_dtype() != want_dtype:
+        raise SeedmiError(f"{LIB_PATH} computes in {'fp16' if lib.seedmi_compute_dtype() else 'bf16'}, expected {'fp16' if want_dtype else 'bf16'}")
     # tuning knobs for experiments: SEEDMI_OPTIONS="gemm_persist=0,gemm_group_m=4" (same keys as seedmi_set_option)
     for kv in filter(None, os.environ.get("SEEDMI_OPTIONS", "").split(",")):
         key, _, val = kv.partition("=")
@@ -167,9 +197,10 @@ def load():
     return lib
 
 
-def check(rc, what=""):
+def check(rc, what="", lib=None):
+    """``lib``: the library the failing call was made through (each build keeps its own error string); default: the bf16 build."""
     if rc != 0:
-        msg = load().seedmi_last_error().decode(errors="replace")
+        msg = (lib or load()).seedmi_last_error().decode(errors="replace")
         raise SeedmiError(f"{what} failed with code {rc}: {msg}")
 
 

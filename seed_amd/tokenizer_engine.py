@@ -4,7 +4,7 @@ Mirrors ``Blip2QformerQuantizer`` (models/seed_qformer/qformer_quantizer.py:161-
 path only.  ``load_state_dict``-compatible: it consumes the reference's key names
 (``visual_encoder.blocks.N.attn.qkv.weight`` ...) and repacks them once:
 
-* every tensor -> bf16, contiguous, device resident (2.18 GB at full size);
+* every tensor -> the engine's 16-bit dtype (bf16 by default, fp16 on request), contiguous, device resident (2.18 GB at full size);
 * ``patch_embed.proj.weight`` [D,3,14,14] -> [D, 640] (K = 588 zero padded to the GEMM's K-tile);
 * ViT qkv bias = cat(q_bias, 0, v_bias) built once instead of per call (eva_vit.py:133);
 * Q-Former self-attention q/k/v stacked to one [3Q,Q] GEMM, cross-attention k/v to one [2Q,D] GEMM;
@@ -28,8 +28,15 @@ def _round_up(x, m):
 
 
 class TokenizerEngine:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: TokenizerConfig, device="cuda", fold_layernorm: bool = True):
-        self.lib = L.load()
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: TokenizerConfig, device="cuda", fold_layernorm: bool = True,
+                 dtype: torch.dtype = torch.bfloat16):
+        # dtype: the 16-bit element the whole path computes in - torch.bfloat16 (BASELINE.json's configs; libseedmi.so) or torch.float16
+        # (the reference's shipped `fp16: True`, configs/tokenizer/seed_llama_tokenizer_hf.yaml:3; libseedmi_f16.so: same kernels, same
+        # rounding places, fp16 as the element)
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise L.SeedmiError(f"TokenizerEngine computes in bfloat16 or float16, not {dtype}")
+        self.dtype = dtype
+        self.lib = L.load(dtype)
         self.cfg = cfg
         # fold_layernorm: norm1 / norm2 of every ViT block are applied inside the qkv / fc1 GEMMs (seedmi_gemm_bf16_ext) instead of
         # as separate passes over the token stream; False keeps the explicit LayerNorm launches (A/B, tests)
@@ -40,7 +47,7 @@ class TokenizerEngine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(self.device):
-            L.check(self.lib.seedmi_check_device(), "seedmi_check_device")
+            L.check(self.lib.seedmi_check_device(), "seedmi_check_device", self.lib)
         self._keep = []          # tensors owning the device memory referenced by the C structs
         self._ws = None
         self._ws_batch = 0
@@ -49,7 +56,7 @@ class TokenizerEngine:
 
     # ------------------------------------------------------------------ packing
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
-        t = t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+        t = t.detach().to(device=self.device, dtype=self.dtype).contiguous()
         self._keep.append(t)
         return t
 
@@ -63,12 +70,12 @@ class TokenizerEngine:
         LN(x) W^T + b = rstd * (x (W * gamma)^T - mean * colsum) + (b + W beta).  The GEMM multiplies the half residual stream by
         W' = half(W * gamma); colsum is taken over the ROUNDED W' so that the mean term cancels exactly what the MFMAs summed.
         Everything on the parameters' device in fp32 (the weights are the model's half parameters)."""
-        w32 = weight.detach().to(self.device).to(torch.bfloat16).float()
-        g32 = gamma.detach().to(self.device).to(torch.bfloat16).float()
-        b32 = beta.detach().to(self.device).to(torch.bfloat16).float()
-        wg = (w32 * g32.unsqueeze(0)).to(torch.bfloat16)
+        w32 = weight.detach().to(self.device).to(self.dtype).float()
+        g32 = gamma.detach().to(self.device).to(self.dtype).float()
+        b32 = beta.detach().to(self.device).to(self.dtype).float()
+        wg = (w32 * g32.unsqueeze(0)).to(self.dtype)
         colsum = wg.float().sum(dim=1)
-        bias32 = bias.detach().to(self.device).to(torch.bfloat16).float() + w32 @ b32
+        bias32 = bias.detach().to(self.device).to(self.dtype).float() + w32 @ b32
         self._keep += [wg]
         return wg.contiguous(), self._dev32(colsum), self._dev32(bias32)
 
@@ -94,7 +101,7 @@ class TokenizerEngine:
         w.pos_embed = p(self._dev(pos))
         cls = g("visual_encoder.cls_token").reshape(D)
         # half(cls) + half(pos[0]) rounded once more: what `x + self.pos_embed` does on the cls row (eva_vit.py:373-376)
-        cls_pos0 = (cls.to(torch.bfloat16).float() + pos[0].to(torch.bfloat16).float())
+        cls_pos0 = (cls.to(self.dtype).float() + pos[0].to(self.dtype).float())
         w.cls_pos0 = p(self._dev(cls_pos0))
 
         vit = (L.VitLayer * cfg.vit_depth)()
@@ -155,7 +162,7 @@ class TokenizerEngine:
         ew, eb = self._dev(g(e + "weight")), self._dev(g(e + "bias"))
         with torch.cuda.device(self.device):
             L.check(self.lib.seedmi_layernorm_bf16(L.ptr(qt), Q, L.ptr(ew), L.ptr(eb), 1e-12, L.ptr(q_ln), Q,
-                                                   cfg.n_query, Q, L.stream_ptr()), "layernorm(query_tokens)")
+                                                   cfg.n_query, Q, L.stream_ptr()), "layernorm(query_tokens)", self.lib)
         w.query_ln = p(q_ln)
 
         w.head_w0, w.head_b0 = p(self._dev(g("encode_task_layer.0.weight"))), p(self._dev(g("encode_task_layer.0.bias")))
@@ -170,7 +177,7 @@ class TokenizerEngine:
         self.code_sqnorm = torch.empty(cfg.n_embed, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             L.check(self.lib.seedmi_vq_code_sqnorm(L.ptr(self.codebook), L.ptr(self.code_sqnorm), cfg.n_embed,
-                                                   cfg.code_dim, L.stream_ptr()), "seedmi_vq_code_sqnorm")
+                                                   cfg.code_dim, L.stream_ptr()), "seedmi_vq_code_sqnorm", self.lib)
         self.w.codebook = L.ptr(self.codebook)
         self.w.code_sqnorm = L.ptr(self.code_sqnorm)
 
@@ -183,7 +190,7 @@ class TokenizerEngine:
         return self._ws
 
     def encode(self, images: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-        """images [B,3,S,S] float (fp32 or bf16; other float types are widened to fp32) on this engine's device.
+        """images [B,3,S,S] float (fp32 or the engine's 16-bit dtype; other float types are widened to fp32) on this engine's device.
         Returns int64 [B, n_query] on the same device (stream ordered, no host sync)."""
         cfg = self.cfg
         if images.dim() == 3:                       # seed_llama_tokenizer.py:81-82
@@ -195,7 +202,7 @@ class TokenizerEngine:
         if images.device != self.device:
             raise L.SeedmiError(f"images on {images.device}, engine on {self.device} (the caller places the tensor, "
                                 "seed_llama_tokenizer.py:84-85)")
-        if images.dtype not in (torch.float32, torch.bfloat16):
+        if images.dtype not in (torch.float32, self.dtype):
             images = images.float()
         images = images.contiguous()
         B = images.shape[0]
@@ -208,9 +215,9 @@ class TokenizerEngine:
         tp = None
         if taps is not None:
             t = L.TokenizerTaps()
-            emb = torch.empty(B * cfg.n_tokens, cfg.vit_dim, dtype=torch.bfloat16, device=self.device)
-            qo = torch.empty(B * cfg.n_query, cfg.qf_dim, dtype=torch.bfloat16, device=self.device)
-            z = torch.empty(B * cfg.n_query, cfg.code_dim, dtype=torch.bfloat16, device=self.device)
+            emb = torch.empty(B * cfg.n_tokens, cfg.vit_dim, dtype=self.dtype, device=self.device)
+            qo = torch.empty(B * cfg.n_query, cfg.qf_dim, dtype=self.dtype, device=self.device)
+            z = torch.empty(B * cfg.n_query, cfg.code_dim, dtype=self.dtype, device=self.device)
             t.image_embeds, t.qformer_out, t.z = L.ptr(emb), L.ptr(qo), L.ptr(z)
             taps.update(image_embeds=emb.view(B, cfg.n_tokens, -1), qformer_out=qo.view(B, cfg.n_query, -1),
                         z=z.view(B, cfg.n_query, -1))
@@ -218,5 +225,5 @@ class TokenizerEngine:
         with torch.cuda.device(self.device):
             rc = self.lib.seedmi_tokenize(C.byref(self.w), L.ptr(images), 1 if images.dtype == torch.float32 else 0, B,
                                           L.ptr(ids), tp, L.ptr(ws), ws.numel(), L.stream_ptr())
-        L.check(rc, "seedmi_tokenize")
+        L.check(rc, "seedmi_tokenize", self.lib)
         return ids

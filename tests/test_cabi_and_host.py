@@ -132,12 +132,18 @@ def test_argument_validation_returns_status_codes_and_messages():
     assert l.seedmi_set_option(b"no_such_option", 1) == E_SHAPE and "no_such_option" in err()
     assert l.seedmi_set_option(b"tokenize_streams", 9) == E_SHAPE
     # the ViT attention's kernel selection and the round-4 options documented in the header: accepted ranges, defaults restored
-    for v in range(0, 8):
+    for v in (0, 1, 2, 3, 5):
         assert l.seedmi_set_option(b"attn_vit", v) == 0
-    assert l.seedmi_set_option(b"attn_vit", 8) == E_SHAPE and l.seedmi_set_option(b"attn_vit", -1) == E_SHAPE
+    # the product library keeps the bit-preserving selectors only: the "flash" variants (4, 6: another rounding
+    # point), the priority-less arm (7), the schedules' history and the A/B knobs live in libseedmi_dev.so
+    for v in (4, 6, 7, 8, -1):
+        assert l.seedmi_set_option(b"attn_vit", v) == E_SHAPE
+    for key, v in ((b"gemm_sched", 81), (b"gemm_sched", 31), (b"gemm_residual_nt", 0), (b"gemm_prefetch_residual", 1), (b"tokenize_tile_stats", 1),
+                   (b"skinny_waves", 4), (b"skinny_rows", 1), (b"skinny_nt", 1), (b"decode_persistent", 1), (b"prefill_streamk", 1), (b"gemm_ablate", 32)):
+        assert l.seedmi_set_option(key, v) == E_SHAPE, (key, v)
     assert l.seedmi_set_option(b"attn_vit", 5) == 0                      # the default (staggered 16-wave kernel)
     assert l.seedmi_set_option(b"attn_xcd", 0) == 0 and l.seedmi_set_option(b"attn_xcd", 2) == E_SHAPE and l.seedmi_set_option(b"attn_xcd", 1) == 0
-    assert l.seedmi_set_option(b"gemm_sched", 81) == 0 and l.seedmi_set_option(b"gemm_sched", 8273) == 0
+    assert l.seedmi_set_option(b"gemm_sched", 0) == 0 and l.seedmi_set_option(b"gemm_sched", 24657) == 0 and l.seedmi_set_option(b"gemm_sched", 8273) == 0
     assert l.seedmi_set_option(b"gemm_sched", 65536) == E_SHAPE and l.seedmi_set_option(b"gemm_sched", -1) == 0
     with pytest.raises(lib.SeedmiError, match="unknown option"):
         lib.check(l.seedmi_set_option(b"gemm", 7), "seedmi_set_option")
@@ -184,6 +190,18 @@ ids = tokenize_data_parallel(fake_encode, images, dist)
 assert ids.shape == (7, 32) and torch.equal(ids, fake_encode(images)), "DP result differs from single-process result"
 eq = gather_token_ids(torch.full((4, 32), rank, dtype=torch.int64), dist)
 assert eq.shape == (8, 32) and (eq[:4] == 0).all() and (eq[4:] == 1).all()
+# the wire format is int16 (ids < 8192), widened back to the caller's int64 on arrival; the extremes of the codebook range survive it,
+# the int64 wire gives the same result, and ids outside the int16 range are refused instead of truncated
+edge = torch.tensor([[0, 8191, 4096 + rank] + [7] * 29], dtype=torch.int64)
+a, b = gather_token_ids(edge, dist), gather_token_ids(edge, dist, wire_int16=False)
+assert a.dtype == torch.int64 and torch.equal(a, b) and a[0, 1] == 8191 and a[1, 2] == 4097
+import seed_amd.dist as D
+assert D.WIRE_DTYPE == torch.int16
+try:
+    gather_token_ids(torch.full((1, 32), 40000, dtype=torch.int64), dist)
+    raise SystemExit("an id beyond the int16 range was not refused")
+except ValueError:
+    pass
 dist.barrier()
 dist.destroy_process_group()
 print("ok", rank)

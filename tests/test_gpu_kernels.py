@@ -69,12 +69,12 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[128, 256, (256, 0), (256, 81), (256, 8273), (256, 24657), (256, 57425)],
-                ids=["gemm128", "gemm256", "gemm256_sched0", "gemm256_sched81", "gemm256_sched8273", "gemm256_seam", "gemm256_peel"])
+@pytest.fixture(params=[128, 256, (256, 0), (256, 24657), (256, 57425)],
+                ids=["gemm128", "gemm256", "gemm256_sched0", "gemm256_seam", "gemm256_peel"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (128x128 two-barrier and 256x256 staggered deep pipeline), the 256x256 kernel
     under its default schedule (gemm_sched 8273: two-phase K-tile, position-free body, round 4), under the round-2 schedule (0) and
-    under the round-3 default (81, position-guarded requests) that both stay selectable."""
+    under round 5's seam (24657) and seam + peeled store-tolerant K-tiles (57425) - the values the product library keeps selectable."""
     variant, sched = request.param if isinstance(request.param, tuple) else (request.param, -1)
     L.check(lib.seedmi_set_option(b"gemm", variant), "set_option")
     L.check(lib.seedmi_set_option(b"gemm_sched", sched), "set_option")
@@ -309,7 +309,7 @@ def test_gemm_residual_emits_layernorm_statistics(lib, gemm_variant):
     assert torch.allclose(stats[:, 1].cpu().double(), torch.rsqrt(y.var(1, unbiased=False) + 1e-6), rtol=1e-4)
 
 
-@pytest.mark.parametrize("sched", [0, 31, -1], ids=["sched0", "sched31", "default"])
+@pytest.mark.parametrize("sched", [0, -1], ids=["sched0", "default"])
 def test_layernorm_statistics_by_tile_with_outlier_channels(lib, sched):
     """The LayerNorm fold chain as the tokenizer runs it at large batch (eva_vit.py:199-202): proj / fc2 (BIAS_RESIDUAL) emit one
     (sum, sum of squares) pair per row and 256-column TILE, the consuming qkv / fc1 GEMM finalizes its tiles' rows itself - no
@@ -508,15 +508,14 @@ DEFAULT_ATTN_VIT = 5          # the library's default ViT attention kernel (seed
     (4, 12, 64, 32, 257, False),      # Q-Former cross-attention
     (2, 2, 64, 17, 17, False),
 ])
-@pytest.mark.parametrize("trv", [7, 6, 5, 4, 3, 2, 1, 0], ids=["vit_16wave_staggered_flash", "vit_16wave_staggered", "vit_16wave_flash", "vit_16wave_wide", "vit_16wave",
-                                                            "vit_pipeline", "tr_read", "vt_image"])
+@pytest.mark.parametrize("trv", [6, 4, 3, 2, 1, 0], ids=["vit_16wave_staggered", "vit_16wave_wide", "vit_16wave", "vit_pipeline", "tr_read", "vt_image"])
 def test_attention_fullrow(lib, B, H, hd, nq, nk, causal, trv):
     if trv >= 3 and not (nq == nk == 257 and hd == 88 and not causal):
         pytest.skip("the 16-wave kernel serves the 257-token ViT shape only (other shapes take the same kernels as vit_pipeline)")
-    if B == 72 and trv not in (6, 7, 4):
+    if B == 72 and trv not in (6, 4):
         pytest.skip("the 72-image case exists for the staggered kernel's XCD-aware walk (and one lock-step run beside it)")
     default_vit = DEFAULT_ATTN_VIT
-    L.check(lib.seedmi_set_option(b"attn_vit", {7: 6, 6: 5, 5: 4, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "set_option")
+    L.check(lib.seedmi_set_option(b"attn_vit", {6: 5, 4: 3, 3: 2, 2: 1}.get(trv, 0)), "set_option")
     L.check(lib.seedmi_set_option(b"attn_trv", min(trv, 1)), "set_option")
     gen = torch.Generator().manual_seed(B * 100 + nk)
     C = H * hd
@@ -540,9 +539,10 @@ def test_attention_fullrow(lib, B, H, hd, nq, nk, causal, trv):
     vf = V[:, :C].float().reshape(B, nk, C)
     want = ref_attention(qf, kf, vf, H, scale, causal)
     lib.seedmi_set_option(b"attn_trv", 1)
-    if trv in (6, 7):
+    if trv == 6:
         # the staggered form does every wave's work exactly as the lock-step 16-wave kernel does: bit-identical, row 256 included
-        lib.seedmi_set_option(b"attn_vit", 3 if trv == 6 else 4)
+        # (the "flash"-normalisation pair 4 / 6 of attn_vit moves a rounding point and lives in the devtools build only)
+        lib.seedmi_set_option(b"attn_vit", 3)
         ref16 = torch.full_like(out, float("nan"))
         L.check(lib.seedmi_attention_bf16(L.ptr(Q), ldq, L.ptr(K), ld, L.ptr(V), ld, L.ptr(ref16), C, B, H, hd, nq, nk, scale, 0, 1,
                                           L.stream_ptr()), "attention")

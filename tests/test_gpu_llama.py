@@ -385,6 +385,108 @@ def test_llama14b_width_parity_with_oracle():
     _check_logits(step[:, 0], a32[:, -1], a16[:, -1], "14B-width decode step 1")
 
 
+def test_llama14b_full_depth_parity():
+    """VERDICT r4 item 4 / BASELINE.json config 5 at FULL depth: SEED-LLaMA-14B (LLaMA-2-13B body: 40 layers, hidden 5120, 40 heads x 128,
+    FFN 13824, rms eps 1e-5, vocab 40194), B = 2 sequences of T = 649 built exactly as bench.py's config-5 leg builds them, on the PEAKED
+    ("successor") weights, so that token parity is asserted on most positions.  One prefill with the KV cache written - logits at
+    positions {0, 128, 161, 162, 648} (BOS, <img>, last image code, </img>, last) - then 16 greedy decode steps through the folded-norm
+    hipGraph path (the config's decode side), teacher-forced through the eager path for their logits.  Oracle: O.llama_forward as ONE
+    causal forward over prompt + the engine's tokens, fp32 and bf16 (llama_xformer.py:496-627, 661-743).  Asserted under _check_logits
+    (widened by the bf16 oracle's own distance, as at 8B); SURVEY 8d's un-widened tolerance is REPORTED beside it
+    (profiles/r05_llama14b_depth_parity.json)."""
+    import gc
+    import json
+    import time
+    from seed_amd.weights import make_llama_successor_state_dict
+    cfg = C.LLAMA_14B
+    B, T, n_steps = 2, 649, 16
+    # embed_std 2.0: measured with the oracle at these dims / 40 layers (fp32 vs bf16, 40 positions): 0.95 of the positions confident
+    # (1.2, the 8B value: 0.10 - the 40-layer, 5120-wide body adds more to the stream; 3.0: 1.00)
+    sd, successor = make_llama_successor_state_dict(cfg, seed=0, device="cuda", dtype=torch.bfloat16, norm_jitter=0.05, embed_std=2.0)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(3, 32000, (B, T), generator=g)
+    ids[:, 0] = 1
+    for r in range(4):
+        s0 = 1 + r * (128 + 34) + 128
+        ids[:, s0] = 32000 + 8192
+        ids[:, s0 + 1:s0 + 33] = 32000 + torch.randint(0, 8192, (B, 32), generator=g)
+        ids[:, s0 + 33] = 32000 + 8193
+    probes = (0, 128, 161, 162, 648)
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=704, fold_norm=True)
+    allpos = eng.forward(ids.cuda())                                                        # the reference's API: logits of every position
+    torch.cuda.synchronize()
+    kept_prefill = {p_: allpos[:, p_].float().cpu() for p_ in probes}
+    hip_argmax_prefill = allpos.float().argmax(-1).cpu()
+    del allpos
+    graphed = eng.greedy_decode_graph(ids.cuda(), n_steps + 1).clone()                      # t_1 .. t_17: 16 decode steps behind the prefill
+    torch.cuda.synchronize()
+    eng.reset()
+    lg = eng.forward(ids.cuda(), last_only=True)
+    eager = [lg[:, 0].float().argmax(-1)]
+    kept_step = {}
+    for i in range(1, n_steps + 1):
+        lg = eng.forward(graphed[:, i - 1:i], last_only=True)
+        kept_step[i] = lg[:, 0].float().cpu()
+        eager.append(lg[:, 0].float().argmax(-1))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack(eager, dim=1), graphed), "teacher-forced eager path and hipGraph replay disagree"
+    eng.decode_status(B)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    del eng, sd
+    gc.collect()
+    torch.cuda.empty_cache()
+    seq = torch.cat([ids, graphed[:, :n_steps].cpu()], dim=1)                               # [B, 649 + 16]
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))                                     # (torch's CPU GEMMs lose to oversubscription beyond ~32)
+    try:
+        t0 = time.time()
+        l32, _ = O.llama_forward(sd_cpu, cfg, seq, mode="fp32")
+        l16, _ = O.llama_forward(sd_cpu, cfg, seq, mode="bf16")
+        oracle_s = time.time() - t0
+    finally:
+        torch.set_num_threads(nthreads)
+    report = {"model": "SEED-LLaMA-14B dims, 40 layers, successor weights (embed_std 2.0)", "B": B, "T": T, "decode_steps": n_steps,
+              "oracle_seconds": round(oracle_s, 1), "points": {}}
+
+    def check(got, pos, what):
+        r32, r16 = l32[:, pos], l16[:, pos]
+        _check_logits(got, r32, r16, f"14B full depth {what}")
+        d16 = (got - r16).abs()
+        tol0 = 2e-2 * r16.abs().max() + 2e-2 * r16.abs()
+        tol = tol0 + 2 * (r16 - r32).abs().max()
+        assert (d16 <= tol).all(), (what, d16.max().item(), tol.min().item())
+        report["points"][what] = {"rel_vs_fp32": _rel(got, r32), "rel_bf16_oracle_vs_fp32": _rel(r16, r32), "rel_vs_bf16_oracle": _rel(got, r16),
+                                  "survey_8d_unwidened": {"fraction_of_logits_within": (d16 <= tol0).float().mean().item(),
+                                                          "worst_error_over_tolerance": (d16 / tol0).max().item(),
+                                                          "bf16_oracle_vs_fp32_worst_over_tolerance": ((r16 - r32).abs() / tol0).max().item()}}
+    for p_ in probes:
+        check(kept_prefill[p_], p_, f"prefill position {p_}")
+    for i in (1, 2, 8, 16):
+        check(kept_step[i], T - 1 + i, f"decode step {i}")
+    # token evidence: every prefill position (next-token argmax) and every decode step vs the fp32 oracle, on confident rows
+    top2 = l32.topk(2, dim=-1).values
+    gap = top2[..., 0] - top2[..., 1]
+    confident = gap > 3.0 * (l16 - l32).abs().amax(-1)
+    hip_ids = torch.cat([hip_argmax_prefill, graphed[:, 1:n_steps + 1].cpu()], dim=1)       # argmax after each of the 665 contexts
+    same = hip_ids == l32.argmax(-1)
+    same16 = l16.argmax(-1) == l32.argmax(-1)
+    frac = confident.float().mean().item()
+    hit = l32.argmax(-1) == successor.cpu()[seq]
+    report.update({"confident_fraction": frac, "greedy_agreement": same.float().mean().item(),
+                   "greedy_agreement_bf16_oracle": same16.float().mean().item(),
+                   "hip_differs_on_confident": int((~same & confident).sum()),
+                   "fp32_oracle_emits_the_successor": hit.float().mean().item()})
+    print(f"[14B full depth] confident {frac:.3f}, argmax agreement with the fp32 oracle: hip {report['greedy_agreement']:.3f} / bf16 oracle "
+          f"{report['greedy_agreement_bf16_oracle']:.3f} over {same.numel()} positions; oracle {oracle_s:.1f} s")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(report, open(os.path.join(out, "llama14b_depth_parity.json"), "w"), indent=1)
+    assert frac >= 0.5, f"only {frac:.3f} of the positions are confident: the peaked state dict is not peaked enough at 14B depth"
+    assert (same | ~confident).all(), f"{(~same & confident).sum().item()} argmax ids differ from the fp32 oracle on confident rows"
+    assert (hit | ~confident).float().mean().item() > 0.98
+    assert (~same).sum() <= (~same16).sum() * 1.25 + 3, ((~same).sum().item(), (~same16).sum().item())
+
+
 def test_persistent_decode_layers_are_bit_identical():
     """Devtools build, seedmi_set_option("decode_persistent", 1): all decoder layers of a decode step in one persistent launch (grid barriers instead of
     kernel boundaries, llama_xformer.py:280-332 per layer).  Same tile functions as the per-phase launches, so logits, the KV cache and

@@ -27,8 +27,10 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def _check_against_oracle(cfg, sd, img, tag):
-    eng = TokenizerEngine(sd, cfg, device="cuda")
+def _check_against_oracle(cfg, sd, img, tag, mode="bf16"):
+    """mode: the 16-bit element of BOTH the engine and the same-precision oracle - "bf16" (BASELINE.json's configs) or "fp16" (the
+    reference's shipped setting; libseedmi_f16.so)."""
+    eng = TokenizerEngine(sd, cfg, device="cuda", dtype=torch.bfloat16 if mode == "bf16" else torch.float16)
     taps = {}
     ids = eng.encode(img.cuda(), taps)
     torch.cuda.synchronize()
@@ -36,7 +38,7 @@ def _check_against_oracle(cfg, sd, img, tag):
     assert int(ids.min()) >= 0 and int(ids.max()) < cfg.n_embed
     t32, t16 = {}, {}
     ids32 = O.get_codebook_indices(sd, img, cfg, "fp32", t32)
-    ids16 = O.get_codebook_indices(sd, img, cfg, "bf16", t16)
+    ids16 = O.get_codebook_indices(sd, img, cfg, mode, t16)
     z = taps["z"].float().cpu()
     e_emb = _rel(taps["image_embeds"].float(), t32["image_embeds"])
     e_emb16 = _rel(t16["image_embeds"], t32["image_embeds"])
@@ -48,13 +50,13 @@ def _check_against_oracle(cfg, sd, img, tag):
     assert e_emb < max(1.5 * e_emb16, 2e-3), (e_emb, e_emb16)
     assert e_z < max(1.5 * e_z16, 3e-3), (e_z, e_z16)
     # (2) VQ on the HIP path's own z is bit-exact
-    ids_same_z = O.vq_argmin(z, sd["quantize.embedding.weight"], O.Prec("bf16")).reshape(ids.shape)
+    ids_same_z = O.vq_argmin(z, sd["quantize.embedding.weight"], O.Prec(mode)).reshape(ids.shape)
     assert torch.equal(ids.cpu(), ids_same_z), f"{(ids.cpu() != ids_same_z).sum().item()} ids differ from oracle VQ on the same z"
     # (3) end-to-end ids vs the oracle, margin-gated: |d_hip(e) - d_oracle(e)| <= 2*|dz|*(|z|+|e|)max + bf16 quantisation of d
     cb = sd["quantize.embedding.weight"].float()
     dz = (z - t16["z"]).reshape(-1, cfg.code_dim).norm(dim=1)
     zn = t16["z"].reshape(-1, cfg.code_dim).norm(dim=1)
-    bound = 2 * (2 * dz * (zn + cb.norm(dim=1).max())) + 4 * (zn ** 2 + cb.norm(dim=1).max() ** 2) * 2.0 ** -8
+    bound = 2 * (2 * dz * (zn + cb.norm(dim=1).max())) + 4 * (zn ** 2 + cb.norm(dim=1).max() ** 2) * (2.0 ** -8 if mode == "bf16" else 2.0 ** -11)
     gap16 = t16["vq_gap"].reshape(-1)
     differ16 = (ids.cpu() != ids16).reshape(-1)
     differ32 = (ids.cpu() != ids32).reshape(-1)
@@ -91,6 +93,75 @@ def test_tokenizer_matches_oracle_and_reference_golden(golden_dir, name, cfg):
     assert torch.equal(idsb, ids)
     with pytest.raises(AssertionError):
         eng.encode(torch.zeros(1, 3, cfg.img_size + 14, cfg.img_size, device="cuda"))
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny", C.TINY), ("mid", C.MID)])
+def test_tokenizer_fp16_matches_fp16_oracle_and_reference_golden(golden_dir, name, cfg):
+    """the reference's SHIPPED compute type (configs/tokenizer/seed_llama_tokenizer_hf.yaml:3 `fp16: True`) through
+    libseedmi_f16.so - the same kernels with IEEE fp16 as the 16-bit element (v_mfma_f32_16x16x32_f16, fp16 rounding points) - under the
+    same three-part contract as the bf16 path, against the oracle in its "fp16" choreography and against what the reference's own modules
+    produce in native fp16 (tests/golden/tokenizer_<name>_fp16.npz, oracle/make_golden.py::tokenizer_golden_fp16)."""
+    g = np.load(os.path.join(golden_dir, f"tokenizer_{name}_fp16.npz"))
+    sd = make_tokenizer_state_dict(cfg, seed=int(g["seed_w"]), ln_jitter=float(g["ln_jitter"]))
+    sd["quantize.embedding.weight"] = torch.from_numpy(g["codebook"])
+    img = torch.randn(int(g["batch"]), 3, cfg.img_size, cfg.img_size, generator=torch.Generator().manual_seed(int(g["seed_x"])))
+    assert abs(img.double().sum().item() - float(g["image_sum"])) < 1e-6
+    eng, ids, taps = _check_against_oracle(cfg, sd, img, name + "-fp16", mode="fp16")
+    assert eng.lib.seedmi_compute_dtype() == 1 and taps["z"].dtype == torch.float16
+    z_ref = torch.from_numpy(g["z_fp16"])
+    e = _rel(taps["z"].float(), z_ref)
+    agree = (ids.cpu().numpy() == g["ids_fp16"]).mean()
+    agree32 = (ids.cpu().numpy() == g["ids_fp32"]).mean()
+    print(f"[{name}-fp16] z rel vs the reference's own fp16 run {e:.3e}; ids agree with its fp16 run {agree:.4f}, with its fp32 run {agree32:.4f} "
+          f"(reference fp16 vs fp32: {(g['ids_fp16'] == g['ids_fp32']).mean():.4f})")
+    assert e < 2e-3 and agree > 0.9
+    assert torch.equal(eng.encode(img.cuda()), ids)                      # deterministic
+    assert torch.equal(eng.encode(img.cuda().half()), ids)               # fp16 input: the other im2col path
+    # the two builds coexist in one process: the bf16 engine is unaffected by the fp16 one having been loaded
+    eng_b = TokenizerEngine(sd, cfg, device="cuda")
+    assert eng_b.lib.seedmi_compute_dtype() == 0 and eng_b.lib is not eng.lib
+    tb = {}
+    eng_b.encode(img.cuda(), tb)
+    assert tb["z"].dtype == torch.bfloat16 and _rel(tb["z"].float(), taps["z"].float()) < 2e-2
+
+
+def test_tokenizer_full_size_seed2_fp16(golden_dir):
+    """The full SEED-2 tokenizer in fp16 on the 16 images of tests/golden/tokenizer_full_fp16.npz (the reference's own modules in native
+    fp16): id agreement with the reference AS IT SHIPS, printed next to the bf16 figure of test_tokenizer_full_size_seed2 and recorded
+    in gpurun_out/id_agreement_fp16.json (-> profiles/, BASELINE.md)."""
+    import json
+    path = os.path.join(golden_dir, "tokenizer_full_fp16.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/tokenizer_full_fp16.npz not generated (oracle/make_golden.py)")
+    cfg = C.SEED2
+    g = np.load(path)
+    B = int(g["batch"])
+    sd = make_tokenizer_state_dict(cfg, seed=int(g["seed_w"]))
+    img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(int(g["seed_x"])))
+    assert abs(img.double().sum().item() - float(g["image_sum"])) < 1e-6
+    sd["quantize.embedding.weight"] = calibrate_codebook(torch.from_numpy(g["z_fp32"]), cfg.n_embed, seed=7)
+    eng, ids2, _ = _check_against_oracle(cfg, sd, img[:2], "seed2-full-fp16", mode="fp16")
+    taps = {}
+    ids = eng.encode(img.cuda(), taps)
+    torch.cuda.synchronize()
+    assert torch.equal(ids[:2], ids2)
+    a16 = float((ids.cpu().numpy() == g["ids_fp16"]).mean())
+    a32 = float((ids.cpu().numpy() == g["ids_fp32"]).mean())
+    ref = float((g["ids_fp16"] == g["ids_fp32"]).mean())
+    ez = _rel(taps["z"].float(), torch.from_numpy(g["z_fp16"]))
+    eng_b = TokenizerEngine(sd, cfg, device="cuda")
+    idsb = eng_b.encode(img.cuda())
+    b16 = float((idsb.cpu().numpy() == g["ids_fp16"]).mean())
+    print(f"[seed2-full-fp16] ids agree with the reference's fp16 run {a16:.4f} (bf16 build vs that run: {b16:.4f}), with its fp32 run {a32:.4f}; "
+          f"reference fp16 vs fp32 {ref:.4f}; z rel vs its fp16 run {ez:.3e}")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({"images": B, "ids": int(ids.numel()), "hip_fp16_vs_reference_fp16": a16, "hip_fp16_vs_reference_fp32": a32,
+               "hip_bf16_vs_reference_fp16": b16, "reference_fp16_vs_fp32": ref, "z_rel_vs_reference_fp16": ez},
+              open(os.path.join(out, "id_agreement_fp16.json"), "w"), indent=1)
+    assert ez < 3e-3
+    assert a16 >= min(0.95, ref - 0.02), (a16, ref)
+    assert a16 >= b16 - 0.01, "the fp16 build agrees with the reference's fp16 run no better than the bf16 build does"
 
 
 # Measured on MI355X (round 2, profiles/r02_id_agreement.json: 16 full-size images, 512 ids): HIP vs the reference modules' bf16 run

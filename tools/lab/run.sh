@@ -15,6 +15,7 @@
 #   prof_bench   rocprofv3 --kernel-trace --stats of bench.py $BENCH_ARGS
 #   smoke        __graft_entry__.smoke()
 #   py:<file>    python <file> (any tool under tools/, arguments in PY_ARGS)
+#   prof:<file>  the same under rocprofv3 --kernel-trace --stats -> <tool>_kernel_stats.csv
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd "$R" || exit 1
 export TMPDIR=/tmp
@@ -47,10 +48,16 @@ for step in "$@"; do
             timeout 600 python bench.py ${BENCH_ARGS} > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/bench.err
             tail -c 3000 $O/bench.json; show $O/bench.err 3 ;;
         prof_bench)
-            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o bench -- python $R/bench.py ${BENCH_ARGS:---steps 5 --warmup 2} > $R/$O/prof_bench.log 2>&1)
+            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o bench -- python $R/bench.py ${BENCH_ARGS:---steps 5 --warmup 2} > $R/$O/prof_bench.log 2>&1)
             echo "rc=$?" >> $O/prof_bench.log; find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
         smoke)
             timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log; show $O/smoke.log 4 ;;
+        prof:*)                                         # rocprofv3 --kernel-trace --stats of any tool: prof:tools/tok_trace.py (arguments in PY_ARGS)
+            f=${step#prof:}; n=$(basename "$f" .py)
+            (cd /tmp && timeout ${PY_TIMEOUT:-600} rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$n -o $n -- python $R/$f ${PY_ARGS} > $R/$O/prof_$n.log 2>&1)
+            echo "rc=$?" >> $O/prof_$n.log
+            st=$(find $O/prof_$n -name "*kernel_stats.csv" | head -1); [ -n "$st" ] && cp "$st" $O/${n}_kernel_stats.csv && head -${PY_TAIL:-16} "$st" | cut -c1-200
+            find $O/prof_$n -name "*.db" -delete 2>/dev/null; find $O/prof_$n -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null ;;
         py:*)
             f=${step#py:}; n=$(basename "$f" .py)
             timeout ${PY_TIMEOUT:-600} python "$f" ${PY_ARGS} > $O/$n.log 2>&1; echo "rc=$?" >> $O/$n.log; show $O/$n.log ${PY_TAIL:-20} ;;
