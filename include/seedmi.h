@@ -66,7 +66,10 @@ int seedmi_check_device(void);
  * exist only in the -DSEEDMI_DEVTOOLS build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE.
  *
  *   key                    values (default first)        what it selects
- * = gemm                   0 | 128 | 256                 tile kernel: by shape | 128x128 | persistent 256x256
+ * = gemm                   0 | 64 | 65 | 128 | 256       tile kernel: by shape | 64x64 deep-ring small-M kernel (65: its four-wave form without
+ *                                                        producer waves) | 128x128 | persistent 256x256
+ * = gemm_small             1 | 0                         the automatic selection may take the 64x64 kernel where 128x128 tiles cannot give every
+ *                                                        CU a workgroup (one image: M = 257)
  * = gemm_sched             -1 = 8273 | 24657 | 57425 | 0 schedule of the 256x256 kernel: two-phase K-tile, position-free body | + seam (the next
  *                                                        tile's operands requested by the K loop's last K-tiles) | + peeled first K-tiles whose
  *                                                        waits leave the output stores in flight | the plain four-phase schedule of round 2

@@ -135,8 +135,11 @@ class LlamaForCausalLM(PreTrainedModel, GenerationMixin):
         from seed_amd.llama_engine import LlamaEngine
         opts = self._engine_opts
         sd = {k: v for k, v in self.state_dict().items()}
+        # the model dtype picks the library build: float16 parameters (the reference's `torch_dtype: fp16`, configs/llm/seed_llama_8b.yaml:4,
+        # model_tools.py:7-8) -> libseedmi_f16.so; bfloat16 (and fp32 checkpoints, narrowed once) -> the default bf16 build
+        pdtype = next(iter(sd.values())).dtype if sd else torch.bfloat16
         eng = LlamaEngine(sd, self._engine_config(), device=device, batch_cap=max(opts["batch_cap"], batch),
-                          tmax=opts["tmax"])
+                          tmax=opts["tmax"], dtype=torch.float16 if pdtype == torch.float16 else torch.bfloat16)
         if opts["free_unpacked"]:
             for p in self.parameters():
                 p.data = torch.empty(0, dtype=p.dtype, device=p.device)

@@ -35,7 +35,7 @@ class ContinuousBatcher:
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)                # column of `hist` / row of `uniforms` within the chunk
         self.hist = torch.zeros(self.B, self.chunk, dtype=torch.int64, device=dev)
         self.uniforms = torch.zeros(self.chunk, self.B, dtype=torch.float32, device=dev) if top_p > 0.0 else None
-        self.logits = torch.empty(self.B, engine.vocab_pad, dtype=torch.bfloat16, device=dev)
+        self.logits = torch.empty(self.B, engine.vocab_pad, dtype=engine.dtype, device=dev)
         # the step's workspace is baked into the captured graph: owned here, never reallocated; prefills use their own
         self._ws = engine.new_workspace(self.lib.seedmi_llama_workspace_bytes(C.byref(engine.w), self.B, 1))
         self._ws_prefill = None
@@ -180,7 +180,7 @@ class ContinuousBatcher:
         ids = req["prompt"].to(eng.device).view(1, -1)
         T0 = ids.shape[1]
         pos = torch.arange(T0, dtype=torch.int64, device=eng.device).view(1, T0)
-        lg = torch.empty(1, eng.vocab_pad, dtype=torch.bfloat16, device=eng.device)
+        lg = torch.empty(1, eng.vocab_pad, dtype=eng.dtype, device=eng.device)
         need = self.lib.seedmi_llama_workspace_bytes(C.byref(eng.w), 1, T0)
         if self._ws_prefill is None or self._ws_prefill.numel() < need:
             self._ws_prefill = eng.new_workspace(need)

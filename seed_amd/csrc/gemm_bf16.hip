@@ -747,6 +747,109 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 
 
 // ======================================================================================================
+// Kernel "gemm64": 64x64x64 block tile for SMALL M - one image through the ViT is M = 257, the reference scripts' own call pattern
+// (scripts/seed_tokenizer_inference.py:26-29); the 128x128 kernel then has 33..144 workgroups for 256 CUs and fc2 (K = 6144) walks
+// 96 K-tiles in each of 33 of them behind a two-deep buffer: 90 us for 17 MB of weights.  The k-ordered fp32 chain of every output
+// element is what keeps a batch of one bit-identical to the same image inside a batch of 256 (the DP sharding property), so K cannot
+// be split; what can be raised is the number of tiles (4x) and the bytes each of them keeps in flight:
+//  * 4 waves stacked along M (16 rows x 64 columns each: the shared epilogue's lane layout with MT = 1), 8 MFMAs per wave and K-tile;
+//  * an LDS ring of NS stages of 16 KiB (A tile | W tile, the 128x128 kernel's swizzled 128-byte rows), filled NS - 1 stages ahead by
+//    LDS-DMA with ONE counted wait and ONE barrier per K-tile: stage kt must have landed (the NS - 2 younger stages stay in flight), the
+//    barrier publishes it and retires every read of stage kt - 1, whose slot takes the request for stage kt + NS - 1;
+//  * position-free body (round 4's lesson): requests beyond the last K-tile re-fetch it, so the wait count never changes;
+//  * NS = 8 (128 KiB, one workgroup per CU) when the tiles do not fill the CUs once - Little's law at ~1.5 us of latency wants ~128 KiB
+//    in flight per CU for ~85 GB/s - and NS = 4 with two workgroups per CU otherwise.
+// Same MFMA orientation, fragment layout and epilogues as the 128x128 kernel: bit-identical results (tests run every GEMM case on it).
+template <int EPI, bool LNF, int NS, bool PROD>
+__global__ __launch_bounds__(PROD ? 512 : 256, NS <= 4 ? 2 : 1) void gemm64_kernel(GemmParams p) {
+    // PROD: four PRODUCER waves (4..7) issue every LDS-DMA request and wait for their landing; the four consumer waves (0..3) never touch
+    // the vector-memory pipe inside the K loop - a request costs its issuing wave 60-185 cycles, which was most of a consumer's K-tile
+    // (8 MFMAs + 10 fragment reads) in the four-wave form.  Same ring, same single barrier per K-tile.
+    constexpr int T64 = 64 * BK * 2;                  // 8 KiB per operand tile
+    constexpr int ST64 = 2 * T64;                     // stage: A tile | W tile
+    constexpr int NT = PROD ? 512 : 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = PROD && wave >= 4;
+    const int sw = PROD ? (wave & 3) : wave;          // staging role: rows [16 sw, 16 sw + 16) of both tiles
+    const int li = lane & 15, g = lane >> 4;
+    // m-tiles fastest: the (few) m-tiles that share a W panel are dispatched next to each other
+    const int tm = (int)blockIdx.x % p.tiles_m, tn = (int)blockIdx.x / p.tiles_m;
+    const int m0 = tm * 64, n0 = tn * 64;
+    uint32_t offA[2], offW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * sw + 8 * j + (lane >> 3);
+        const int cs = lane & 7;
+        offA[j] = 2u * ((uint32_t)min(m0 + row, p.M - 1) * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(row)));
+        offW[j] = 2u * ((uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldw + 8u * (uint32_t)(cs ^ swzW(row)));
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, -1, 0x00020000);
+    if (EPI == EPI_BIAS_GELU && GELU_BY_TABLE) load_gelu_lut(smem + NS * ST64, tid, NT);     // (the K loop's barriers order it before the epilogue)
+    const char* lut = (EPI == EPI_BIAS_GELU) ? smem + NS * ST64 : nullptr;
+    const int nk = p.K / BK;
+    auto stage = [&](int kt) {                        // K-tile min(kt, nk - 1) into ring slot kt % NS
+        char* base = smem + (kt % NS) * ST64 + sw * 2048;
+        const uint32_t koff = 2u * (uint32_t)(min(kt, nk - 1) * BK);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16_buf(rsA, offA[j], koff, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16_buf(rsW, offW[j], koff, base + T64 + j * 1024);
+    };
+    auto wait_stage = [&]() {                         // the oldest stage in flight has landed: the NS - 2 younger ones (4 requests each) stay
+        if (NS == 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (NS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (producer) {
+#pragma unroll
+        for (int kt = 0; kt < NS - 1; ++kt) stage(kt);
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_stage();
+            __builtin_amdgcn_s_barrier();             // stage kt published; the consumers have retired their reads of stage kt - 1
+            stage(kt + NS - 1);                       // into the slot of stage kt - 1
+        }
+        return;                                       // (the epilogue has no barrier; requests still in flight target ring slots only)
+    }
+    // fragment read addresses inside a stage (k-step 0; k-step 1 = ^64)
+    const int ra = 16 * wave + li;
+    const int rdA = ra * 128 + ((g ^ swzA(ra)) << 4);
+    int rdW[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rw = 16 * (li >> 2) + 4 * t + (li & 3);
+        rdW[t] = T64 + rw * 128 + ((g ^ swzW(rw)) << 4);
+    }
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!PROD) {
+#pragma unroll
+        for (int kt = 0; kt < NS - 1; ++kt) stage(kt);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (!PROD) wait_stage();
+        __builtin_amdgcn_s_barrier();
+        if (!PROD) stage(kt + NS - 1);
+        const char* sb = smem + (kt % NS) * ST64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a, w[4];
+            a = *(const bf16x8*)(sb + (rdA ^ (ks << 6)));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = *(const bf16x8*)(sb + (rdW[t] ^ (ks << 6)));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[0][ni] = seedmi_mfma_16x16x32(w[ni], a, acc[0][ni]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the fragments are in registers before the next barrier lets the slot be restaged)
+    }
+    gemm_epilogue<EPI, 1, true, NoHook, LNF>(p, acc, m0 + 16 * wave, n0 + 16 * g, li, lut);
+}
+
+// ======================================================================================================
 // Kernel "gemm256": 256x256x64 block tile, 8 waves (2 along M x 4 along N), 128x64 per wave.
 //
 // Deep-pipelined schedule for one workgroup per CU (128 KiB LDS, 2 waves per SIMD):
@@ -1917,6 +2020,33 @@ int launch_gemm128(const GemmParams& p, hipStream_t stream) {
     return seedmi_check_launch("gemm128");
 }
 
+
+std::atomic<int> g_gemm_small{1};    // "gemm_small": the automatic selection may take the 64x64 kernel (1) or stays with 128x128 / 256x256 (0: A/B)
+std::atomic<int> g_gemm64_prod{1};   // "gemm" = 65 selects the four-wave form of the 64x64 kernel (no producer waves) for A/B; 64 / automatic: producer waves
+
+template <int EPI, bool LNF, int NS, bool PROD>
+int launch_gemm64_ns(GemmParams p, hipStream_t stream) {
+    constexpr int lds = NS * 2 * 64 * BK * 2 + (EPI == EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget of the 64x64 kernel");
+    static bool attr_set[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm64_kernel<EPI, LNF, NS, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm64_kernel<EPI, LNF, NS, PROD>), dim3(p.tiles_m * p.tiles_n), dim3(PROD ? 512 : 256), lds, stream, p);
+    return seedmi_check_launch("gemm64");
+}
+template <int EPI, bool LNF = false>
+int launch_gemm64(GemmParams p, hipStream_t stream) {
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_n = (p.N + 63) / 64;
+    // one workgroup per CU with a deep ring when the tiles do not fill the CUs once; two per CU with half the ring otherwise
+    const bool deep = (long long)p.tiles_m * p.tiles_n <= device_cus(current_device());
+    if (g_gemm64_prod) return deep ? launch_gemm64_ns<EPI, LNF, 8, true>(p, stream) : launch_gemm64_ns<EPI, LNF, 4, true>(p, stream);
+    return deep ? launch_gemm64_ns<EPI, LNF, 8, false>(p, stream) : launch_gemm64_ns<EPI, LNF, 4, false>(p, stream);
+}
+
 template <int EPI, bool LNF = false>
 int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_bytes) {
     // the 256x256 kernel wants at least g_gemm_min_tiles tiles (one per CU is 256): below that the 128x128 kernel's four times
@@ -1925,7 +2055,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
     const bool big = p.M >= 1024 && p.N >= 256 && tiles256 >= g_gemm_min_tiles;
     const int variant = g_gemm_variant;
 #ifdef SEEDMI_DEVTOOLS
-    if (LNF) return (variant == 128) ? launch_gemm128<EPI, LNF>(p, s) : launch_gemm256<EPI, LNF>(p, s, sk_ws, sk_ws_bytes);
+    if (LNF && (variant == 128 || variant == 256)) return (variant == 128) ? launch_gemm128<EPI, LNF>(p, s) : launch_gemm256<EPI, LNF>(p, s, sk_ws, sk_ws_bytes);
     if (variant == 257 && EPI != EPI_SWIGLU && EPI != EPI_PATCH_EMBED) return launch_gemm256k<EPI>(p, s, sk_ws, sk_ws_bytes);
     if (variant == 233 && EPI != EPI_SWIGLU && EPI != EPI_PATCH_EMBED) return launch_gemm256t<EPI>(p, s, sk_ws, sk_ws_bytes);   // two-phase K-tile on 32x32x16
     if (variant == 232) return launch_gemm256x<EPI>(p, s);          // 256x256 tile on v_mfma_f32_32x32x16_bf16
@@ -1939,7 +2069,12 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
     if (variant == 255) return launch_gemm256f<EPI>(p, s);          // 256x256, one barrier per K-tile, free-running waves
 #endif
     const bool use256 = variant == 256 || (variant == 0 && big);
-    return use256 ? launch_gemm256<EPI, LNF>(p, s, sk_ws, sk_ws_bytes) : launch_gemm128<EPI, LNF>(p, s);
+    if (use256) return launch_gemm256<EPI, LNF>(p, s, sk_ws, sk_ws_bytes);
+    // small M (one image: M = 257; a short prompt): when 128x128 tiles cannot give every CU a workgroup, the 64x64 kernel's four times
+    // finer tiling and deep ring do (same bits)
+    const long long tiles128 = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const bool small = variant == 64 || variant == 65 || (variant == 0 && g_gemm_small && tiles128 < device_cus(current_device()));
+    return small ? launch_gemm64<EPI, LNF>(p, s) : launch_gemm128<EPI, LNF>(p, s);
 }
 
 }  // namespace
@@ -1960,8 +2095,9 @@ extern "C" int seedmi_set_option(const char* key, int value) {
 #else
     const bool dev_variant = false;
 #endif
-    if (key && !strcmp(key, "gemm") && (value == 0 || value == 128 || value == 256 || dev_variant)) {
+    if (key && !strcmp(key, "gemm") && (value == 0 || value == 64 || value == 65 || value == 128 || value == 256 || dev_variant)) {
         g_gemm_variant = value;
+        g_gemm64_prod = value != 65;
         return SEEDMI_OK;
     }
 #ifdef SEEDMI_DEVTOOLS
@@ -1972,6 +2108,10 @@ extern "C" int seedmi_set_option(const char* key, int value) {
     if (key && !strcmp(key, "gemm_sched") && sched_ok) {                            // (-1 = the default)
         if (value < 0) value = GEMM_SCHED_DEFAULT;
         g_gemm_sched = value;
+        return SEEDMI_OK;
+    }
+    if (key && !strcmp(key, "gemm_small") && (value == 0 || value == 1)) {
+        g_gemm_small = value;
         return SEEDMI_OK;
     }
     if (key && !strcmp(key, "gemm_group_m") && value >= 0 && value <= 64) {

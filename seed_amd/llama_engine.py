@@ -28,8 +28,13 @@ def _round_up(x, m):
 
 class LlamaEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: LlamaConfig, device="cuda", batch_cap: int = 32,
-                 tmax: Optional[int] = None, decode_packed: bool = True, fold_norm: bool = True):
-        self.lib = L.load()
+                 tmax: Optional[int] = None, decode_packed: bool = True, fold_norm: bool = True, dtype: torch.dtype = torch.bfloat16):
+        # dtype: the model dtype (weights, activations, KV cache, logits): torch.bfloat16 (BASELINE.json; libseedmi.so) or torch.float16
+        # (the reference's `torch_dtype: fp16`, configs/llm/seed_llama_8b.yaml:4; libseedmi_f16.so - same kernels, fp16 as the element)
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise L.SeedmiError(f"LlamaEngine computes in bfloat16 or float16, not {dtype}")
+        self.dtype = dtype
+        self.lib = L.load(dtype)
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -39,7 +44,7 @@ class LlamaEngine:
         if cfg.head_dim != 128:
             raise L.SeedmiError(f"head_dim {cfg.head_dim}: the attention kernels are built for 128")
         with torch.cuda.device(self.device):
-            L.check(self.lib.seedmi_check_device(), "seedmi_check_device")
+            L.check(self.lib.seedmi_check_device(), "seedmi_check_device", self.lib)
         self.batch_cap = batch_cap
         self.decode_packed = decode_packed     # second, fragment-major copy of every weight for the M <= 64 path
         # the fragment-major qkv / gate_up / lm_head copies carry weight * gamma of the RMSNorm in front of them: decode steps
@@ -55,7 +60,7 @@ class LlamaEngine:
         self._pack(state_dict)
 
     def _dev(self, t):
-        t = t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+        t = t.detach().to(device=self.device, dtype=self.dtype).contiguous()
         self._keep.append(t)
         return t
 
@@ -65,11 +70,11 @@ class LlamaEngine:
         if not self.decode_packed:
             return None
         if gamma is not None and self.fold_norm:
-            w = (w.float() * gamma.to(self.device).float().unsqueeze(0)).to(torch.bfloat16).contiguous()
+            w = (w.float() * gamma.to(self.device).float().unsqueeze(0)).to(self.dtype).contiguous()
         N, K = w.shape
-        out = torch.empty(self.lib.seedmi_pack_skinny_weights_bytes(N, K) // 2, dtype=torch.bfloat16, device=self.device)
+        out = torch.empty(self.lib.seedmi_pack_skinny_weights_bytes(N, K) // 2, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
-            L.check(self.lib.seedmi_pack_skinny_weights(L.ptr(w), K, N, K, L.ptr(out), L.stream_ptr()), "pack_skinny")
+            L.check(self.lib.seedmi_pack_skinny_weights(L.ptr(w), K, N, K, L.ptr(out), L.stream_ptr()), "pack_skinny", self.lib)
         self._keep.append(out)
         return out
 
@@ -98,7 +103,7 @@ class LlamaEngine:
             dn = self._dev(sd[pre + "mlp.down_proj.weight"])
             l.gate_up_w, l.down_w = p(gu), p(dn)
             l.gate_up_wp, l.down_wp = p(self._packed(gu, sd[pre + "post_attention_layernorm.weight"])), p(self._packed(dn))
-            kc = torch.zeros(self.batch_cap, cfg.heads, self.tmax, cfg.head_dim, dtype=torch.bfloat16, device=self.device)
+            kc = torch.zeros(self.batch_cap, cfg.heads, self.tmax, cfg.head_dim, dtype=self.dtype, device=self.device)
             vc = torch.zeros_like(kc)
             self.k_cache.append(kc)
             self.v_cache.append(vc)
@@ -106,8 +111,8 @@ class LlamaEngine:
         self._layers = layers
         w.layer = C.cast(layers, C.POINTER(L.LlamaLayer))
         w.norm_w = p(self._dev(sd["model.norm.weight"]))
-        lm = torch.zeros(self.vocab_pad, h, dtype=torch.bfloat16)
-        lm[:cfg.vocab] = sd["lm_head.weight"].to(torch.bfloat16).cpu()
+        lm = torch.zeros(self.vocab_pad, h, dtype=self.dtype)
+        lm[:cfg.vocab] = sd["lm_head.weight"].to(self.dtype).cpu()
         lm = self._dev(lm)
         w.lm_head = p(lm)
         w.lm_head_p = p(self._packed(lm, sd["model.norm.weight"]))
@@ -135,7 +140,7 @@ class LlamaEngine:
         """A llama workspace as the C ABI wants it handed over: allocated, then seedmi_llama_workspace_init (stream-ordered)."""
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            L.check(self.lib.seedmi_llama_workspace_init(L.ptr(ws), ws.numel(), L.stream_ptr()), "seedmi_llama_workspace_init")
+            L.check(self.lib.seedmi_llama_workspace_init(L.ptr(ws), ws.numel(), L.stream_ptr()), "seedmi_llama_workspace_init", self.lib)
         return ws
 
     def reset(self):
@@ -150,7 +155,7 @@ class LlamaEngine:
             return
         with torch.cuda.device(self.device):
             L.check(self.lib.seedmi_llama_decode_status(C.byref(self.w), B, L.ptr(ws), ws.numel(), L.stream_ptr()),
-                    "seedmi_llama_decode_status")
+                    "seedmi_llama_decode_status", self.lib)
 
     def forward(self, input_ids: Optional[torch.Tensor], position_ids: Optional[torch.Tensor] = None,
                 past_len: Optional[int] = None, last_only: bool = False, inputs_embeds: Optional[torch.Tensor] = None,
@@ -171,25 +176,25 @@ class LlamaEngine:
             if inputs_embeds.dim() != 3 or inputs_embeds.shape[2] != cfg.hidden:
                 raise ValueError(f"inputs_embeds must be [batch, seq, {cfg.hidden}]")
             B, T = inputs_embeds.shape[:2]
-            inputs_embeds = inputs_embeds.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            inputs_embeds = inputs_embeds.to(device=self.device, dtype=self.dtype).contiguous()
         if past_len is None:
             past_len = self.past_len
         if position_ids is None:                                                          # llama_xformer.py:531-539
             position_ids = torch.arange(past_len, past_len + T, dtype=torch.int64, device=self.device).unsqueeze(0).expand(B, T)
         position_ids = position_ids.reshape(B, T).to(device=self.device, dtype=torch.int64).contiguous()
         Tout = 1 if last_only else T
-        logits = torch.empty(B * Tout, self.vocab_pad, dtype=torch.bfloat16, device=self.device)
+        logits = torch.empty(B * Tout, self.vocab_pad, dtype=self.dtype, device=self.device)
         hidden = None
         if hidden_states_out is not None:
             if last_only:
                 raise ValueError("hidden states are produced for all positions: last_only must be False")
-            hidden = torch.empty(cfg.layers + 1, B, T, cfg.hidden, dtype=torch.bfloat16, device=self.device)
+            hidden = torch.empty(cfg.layers + 1, B, T, cfg.hidden, dtype=self.dtype, device=self.device)
         ws = self._workspace(B, T)
         with torch.cuda.device(self.device):
             rc = self.lib.seedmi_llama_forward_io(C.byref(self.w), L.ptr(input_ids), L.ptr(inputs_embeds), L.ptr(position_ids),
                                                   B, T, past_len, None, 1 if last_only else 0, L.ptr(logits), self.vocab_pad,
                                                   L.ptr(hidden), L.ptr(ws), ws.numel(), L.stream_ptr())
-        L.check(rc, "seedmi_llama_forward")
+        L.check(rc, "seedmi_llama_forward", self.lib)
         self.past_len = past_len + T
         if hidden is not None:
             hidden_states_out.extend(hidden[i] for i in range(cfg.layers + 1))
@@ -206,7 +211,7 @@ class LlamaEngine:
         cb, ct = min(nb, self.batch_cap), min(nt, self.tmax)
         for i in range(cfg.layers):
             for name, caches in (("k_cache", self.k_cache), ("v_cache", self.v_cache)):
-                new = torch.zeros(nb, cfg.heads, nt, cfg.head_dim, dtype=torch.bfloat16, device=self.device)
+                new = torch.zeros(nb, cfg.heads, nt, cfg.head_dim, dtype=self.dtype, device=self.device)
                 new[:cb, :, :ct] = caches[i][:cb, :, :ct]
                 caches[i] = new
                 setattr(self._layers[i], name, L.ptr(new))
@@ -224,8 +229,8 @@ class LlamaEngine:
         B = tok.shape[0]
         rc = self.lib.seedmi_llama_forward_ex(C.byref(self.w), L.ptr(tok), None, B, 1, self.tmax - 1, L.ptr(counter), 1,
                                               L.ptr(logits), self.vocab_pad, L.ptr(ws), ws.numel(), L.stream_ptr())
-        L.check(rc, "seedmi_llama_forward_ex")
-        L.check(self.lib.seedmi_add_i32(L.ptr(counter), 1, L.stream_ptr()), "seedmi_add_i32")
+        L.check(rc, "seedmi_llama_forward_ex", self.lib)
+        L.check(self.lib.seedmi_add_i32(L.ptr(counter), 1, L.stream_ptr()), "seedmi_add_i32", self.lib)
 
     def select_token(self, logits: torch.Tensor, tok_out: torch.Tensor, top_p: float = 0.0, temperature: float = 1.0,
                      uniforms: Optional[torch.Tensor] = None, step_dev: Optional[torch.Tensor] = None, step_offset: int = 0,
@@ -233,7 +238,7 @@ class LlamaEngine:
         """seedmi_sample_token_bf16 on logits [B, ld] (bf16): greedy (uniforms None / top_p 0) or temperature + top-p with
         the uniform for (step, row) taken from ``uniforms`` [steps, B]; writes tok_out [B] and history[:, step]."""
         B = logits.shape[0]
-        if logits.dtype != torch.bfloat16 or logits.stride(-1) != 1 or tok_out.dtype != torch.int64:
+        if logits.dtype != self.dtype or logits.stride(-1) != 1 or tok_out.dtype != torch.int64:
             raise ValueError("select_token: logits must be bf16 rows, tok_out int64")
         # rows of ``uniforms`` / columns of ``history`` the device-side step may address (0 = no step-indexed buffer)
         n_steps = 0
@@ -246,7 +251,7 @@ class LlamaEngine:
                                                    float(top_p), L.ptr(uniforms), L.ptr(step_dev), int(step_offset),
                                                    L.ptr(tok_out), L.ptr(history), 0 if history is None else history.stride(0),
                                                    n_steps, L.stream_ptr())
-        L.check(rc, "seedmi_sample_token_bf16")
+        L.check(rc, "seedmi_sample_token_bf16", self.lib)
 
     def capture_decode_graph(self, first_tok: torch.Tensor, n_new: int, top_p: float = 0.0, temperature: float = 1.0,
                              uniforms: Optional[torch.Tensor] = None):
@@ -265,7 +270,7 @@ class LlamaEngine:
         out[:, 0:1] = tok
         past0 = self.past_len
         counter = torch.tensor([past0], dtype=torch.int32, device=self.device)
-        logits = torch.empty(B, self.vocab_pad, dtype=torch.bfloat16, device=self.device)
+        logits = torch.empty(B, self.vocab_pad, dtype=self.dtype, device=self.device)
         ws = self._workspace(B, 1)
 
         def body():

@@ -77,6 +77,48 @@ def test_llama_prefill_and_decode(golden_dir, B, T):
     print(f"[greedy B{B}] token agreement {same.float().mean().item():.3f}")
 
 
+@pytest.mark.parametrize("B,T", [(2, 12), (8, 12)])
+def test_llama_fp16_prefill_and_decode(B, T):
+    """VERDICT r4 item 5 on the LLM side: the reference's shipped model dtype (`torch_dtype: fp16`, configs/llm/seed_llama_8b.yaml:4) through
+    libseedmi_f16.so - the same kernels with fp16 as the 16-bit element - against the oracle in fp32 and in its "fp16" choreography
+    (llama_xformer.py:105-113 RMSNorm island, :147-150 RoPE tables cast on read, :718 logits in the model dtype), prefill at both GEMM
+    paths, the KV cache, cached decode steps and the hipGraph-replayed greedy loop."""
+    cfg = C.LLAMA_TINY
+    sd = make_llama_state_dict(cfg, seed=3, norm_jitter=0.05)
+    ids = torch.randint(3, cfg.vocab, (B, T), generator=torch.Generator().manual_seed(6 + B))
+    eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=64, dtype=torch.float16)
+    assert eng.lib.seedmi_compute_dtype() == 1
+    logits = eng.forward(ids.cuda())
+    torch.cuda.synchronize()
+    assert logits.dtype == torch.float16 and tuple(logits.shape) == (B, T, cfg.vocab)
+    l32, past32 = O.llama_forward(sd, cfg, ids, mode="fp32")
+    l16, _ = O.llama_forward(sd, cfg, ids, mode="fp16")
+    _check_logits(logits, l32, l16, f"fp16 prefill B{B}")
+    e16, eb = _rel(logits.float(), l32), _rel(O.llama_forward(sd, cfg, ids, mode="bf16")[0], l32)
+    print(f"[fp16 prefill B{B}] rel vs fp32: fp16 build {e16:.3e}, a bf16 pipeline {eb:.3e}")
+    assert e16 < 0.5 * eb                                   # 11 significand bits against 8: the fp16 build must be the closer one
+    assert _rel(eng.k_cache[0][:B, :, :T].float(), past32[0][0]) < 2e-3
+    assert _rel(eng.v_cache[1][:B, :, :T].float(), past32[1][1]) < 4e-3
+    n_new = 6
+    t32, s32 = O.llama_greedy_decode(sd, cfg, ids, n_new, mode="fp32")
+    eng.reset()
+    lg = eng.forward(ids.cuda(), last_only=True)
+    _check_logits(lg[:, 0], s32[:, 0], s32[:, 0], f"fp16 prefill-last B{B}")
+    for i in range(1, n_new):
+        lg = eng.forward(t32[:, i - 1:i].cuda(), last_only=True)
+        _check_logits(lg[:, 0], s32[:, i], s32[:, i], f"fp16 decode step {i} B{B}")
+    toks, _ = eng.greedy_decode(ids.cuda(), n_new)
+    graphed = eng.greedy_decode_graph(ids.cuda(), n_new)
+    torch.cuda.synchronize()
+    assert torch.equal(toks, graphed), "fp16: hipGraph replay and the eager loop disagree"
+    top2 = s32.topk(2, dim=-1).values
+    confident = (top2[..., 0] - top2[..., 1]) > 1e-2 * s32.abs().amax(-1)
+    same, alive = toks.cpu() == t32, torch.ones(B, dtype=torch.bool)
+    for i in range(n_new):
+        assert (same[:, i] | ~confident[:, i] | ~alive).all(), f"fp16: greedy token differs at confident step {i}"
+        alive &= same[:, i]
+
+
 def test_graph_decode_equals_eager_decode():
     """The hipGraph-replayed decode loop (device-resident cache length) produces exactly the eager loop's tokens."""
     cfg = C.LLAMA_TINY

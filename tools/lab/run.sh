@@ -10,7 +10,7 @@
 #   prefill_ab   tools/prefill_bench.py        AB="gemm_sched=8273|gemm_sched=-1" MODEL=14b|8b
 #   decode_ab    tools/decode_ab.py            DECODE_SETS=...
 #   attn         tools/attn_bench.py
-#   pytest       python -m pytest $PYTEST_ARGS (default: the whole -m gpu suite)
+#   pytest       python -m pytest $PYTEST_ARGS (default: the whole -m gpu suite); PYTEST_K="a or b" adds -k
 #   bench        python bench.py $BENCH_ARGS  -> bench.json
 #   prof_bench   rocprofv3 --kernel-trace --stats of bench.py $BENCH_ARGS
 #   smoke        __graft_entry__.smoke()
@@ -42,7 +42,8 @@ for step in "$@"; do
         attn)
             timeout 300 python tools/attn_bench.py > $O/attn.log 2>&1; echo "rc=$?" >> $O/attn.log; show $O/attn.log 12 ;;
         pytest)
-            timeout ${PYTEST_TIMEOUT:-1500} python -m pytest ${PYTEST_ARGS:-tests -m gpu -q -x} > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+            if [ -n "$PYTEST_K" ]; then timeout ${PYTEST_TIMEOUT:-1500} python -m pytest ${PYTEST_ARGS:-tests -m gpu -q -x} -k "$PYTEST_K" > $O/pytest.log 2>&1
+            else timeout ${PYTEST_TIMEOUT:-1500} python -m pytest ${PYTEST_ARGS:-tests -m gpu -q -x} > $O/pytest.log 2>&1; fi; echo "pytest rc=$?" >> $O/pytest.log
             show $O/pytest.log 12 ;;
         bench)
             timeout 600 python bench.py ${BENCH_ARGS} > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/bench.err
