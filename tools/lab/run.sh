@@ -15,6 +15,7 @@
 #   prof_bench   rocprofv3 --kernel-trace --stats of bench.py $BENCH_ARGS
 #   smoke        __graft_entry__.smoke()
 #   py:<file>    python <file> (any tool under tools/, arguments in PY_ARGS)
+#   sh:<file>    bash <file> (tools/pmc_qkv.sh, tools/pmc_skinny.sh ...)
 #   prof:<file>  the same under rocprofv3 --kernel-trace --stats -> <tool>_kernel_stats.csv
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd "$R" || exit 1
@@ -59,6 +60,9 @@ for step in "$@"; do
             echo "rc=$?" >> $O/prof_$n.log
             st=$(find $O/prof_$n -name "*kernel_stats.csv" | head -1); [ -n "$st" ] && cp "$st" $O/${n}_kernel_stats.csv && head -${PY_TAIL:-16} "$st" | cut -c1-200
             find $O/prof_$n -name "*.db" -delete 2>/dev/null; find $O/prof_$n -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null ;;
+        sh:*)                                           # any shell tool: sh:tools/pmc_qkv.sh
+            f=${step#sh:}; n=$(basename "$f" .sh)
+            timeout ${PY_TIMEOUT:-900} bash "$f" ${PY_ARGS} > $O/$n.log 2>&1; echo "rc=$?" >> $O/$n.log; show $O/$n.log ${PY_TAIL:-24} ;;
         py:*)
             f=${step#py:}; n=$(basename "$f" .py)
             timeout ${PY_TIMEOUT:-600} python "$f" ${PY_ARGS} > $O/$n.log 2>&1; echo "rc=$?" >> $O/$n.log; show $O/$n.log ${PY_TAIL:-20} ;;
