@@ -18,8 +18,8 @@ from seed_amd import lib as L  # noqa: E402
 from seed_amd.llama_engine import LlamaEngine  # noqa: E402
 from seed_amd.weights import make_llama_state_dict  # noqa: E402
 
-DEFAULTS = {"skinny_splitk": 1, "decode_attn_early": 1, "decode_fused": 1, "skinny_rows": 0, "skinny_waves": 0}
-ARMS = sys.argv[1:] or ["", "skinny_splitk=0"]
+DEFAULTS = {"skinny_splitk": 1, "decode_attn_early": 1, "decode_fused": 1}
+ARMS = [("" if a in ("-", "defaults") else a) for a in sys.argv[1:]] or ["", "skinny_splitk=0"]
 STEPS = int(os.environ.get("STEPS", "16"))
 ROUNDS = int(os.environ.get("ROUNDS", "5"))
 OUT = os.environ.get("OUT", "gpurun_out/decode_ab.json")
