@@ -70,6 +70,16 @@ SEEDMI_DEVINL float gelu_erf(float x) {
     const float one_plus_erf = x >= 0.f ? 2.0f - erfc_z : erfc_z;
     return 0.5f * x * one_plus_erf;
 }
+// (mean, rstd) of a row from its column sum and sum of squares: ONE expression for every place that finishes LayerNorm statistics (the
+// finalize kernel, the 256x256 GEMM's in-tile finalize, the small-M consumers' epilogue) - written with the non-contracting intrinsics so
+// that no compiler decision (a fused multiply-add here, none there) can make two of them differ in the last bit: an image must give the same
+// ids whichever kernel its batch size selects.
+SEEDMI_DEVINL float2 seedmi_ln_finish(float s1, float s2, float inv_n, float eps) {
+    const float mean = __fmul_rn(s1, inv_n);
+    const float var = fmaxf(__fsub_rn(__fmul_rn(s2, inv_n), __fmul_rn(mean, mean)), 0.f);
+    return make_float2(mean, rsqrtf(__fadd_rn(var, eps)));
+}
+
 SEEDMI_DEVINL float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 SEEDMI_DEVINL float wave_sum(float v) {

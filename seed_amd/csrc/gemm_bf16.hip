@@ -235,8 +235,22 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
             bias[4 * i] = b4.x; bias[4 * i + 1] = b4.y; bias[4 * i + 2] = b4.z; bias[4 * i + 3] = b4.w;
         }
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-            rstat[mi] = *(const float2*)((const char*)p.ln_stats + 8u * (uint32_t)min(mrow0 + 16 * mi + li, p.M - 1));
+        for (int mi = 0; mi < MT; ++mi) {
+            const uint32_t row = (uint32_t)min(mrow0 + 16 * mi + li, p.M - 1);
+            if (p.ln_planes > 0) {
+                // partial planes (the producer GEMM's span-major (sum, sum of squares) pairs) instead of finished statistics: the row's pairs
+                // summed in plane order and finished exactly as seedmi_layernorm_stats_finalize does - the small-M kernels (64x64, 128x128)
+                // then need no finalize launch between two GEMMs (one image: 77 launches of ~6.7 us)
+                float s1 = 0.f, s2 = 0.f;
+                for (int pl = 0; pl < p.ln_planes; ++pl) {
+                    const float2 t = *(const float2*)((const char*)p.ln_stats + 8 * ((size_t)pl * (size_t)p.ln_ld + row));
+                    s1 += t.x; s2 += t.y;
+                }
+                rstat[mi] = seedmi_ln_finish(s1, s2, p.ln_inv_cols, p.ln_eps);
+            } else {
+                rstat[mi] = *(const float2*)((const char*)p.ln_stats + 8u * row);
+            }
+        }
     } else if (!CONSUME && EPI != EPI_NONE && p.bias) {
         if (full) {
             const uint4 b0 = *(const uint4*)(p.bias + nb);
@@ -1486,9 +1500,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             const char* src = smem + STAT_OFF + FOLD_X_OFF + (r >> 7) * 1024 + 8 * (r & 127);
             float s1 = 0.f, s2 = 0.f;
             for (int pl = 0; pl < p.ln_planes; ++pl) { const float2 t = *(const float2*)(src + 2048 * pl); s1 += t.x; s2 += t.y; }
-            const float mean = s1 * p.ln_inv_cols;
-            const float var = fmaxf(s2 * p.ln_inv_cols - mean * mean, 0.f);
-            *(float2*)(smem + STAT_OFF + FOLD_FIN_OFF + 8 * r) = make_float2(mean, rsqrtf(var + p.ln_eps));
+            *(float2*)(smem + STAT_OFF + FOLD_FIN_OFF + 8 * r) = seedmi_ln_finish(s1, s2, p.ln_inv_cols, p.ln_eps);
         }
     };
 
@@ -2198,8 +2210,12 @@ extern "C" int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda,
     }
     if (ext && (ext->stats_by_tile || ext->ln_planes > 0)) {
         const bool prod_ok = !ext->stats_by_tile || (ext->stats_out && (ext->stats_ld % 2) == 0);
-        const bool cons_ok = ext->ln_planes <= 0 || (lnf && ext->ln_planes <= FOLD_MAX_PLANES && ext->ln_ld >= M && (ext->ln_ld % 2) == 0 && ext->ln_cols > 0);
-        if (!prod_ok || !cons_ok || !gemm_uses_256(M, N)) {
+        // consumer planes: the 256x256 kernel takes up to FOLD_MAX_PLANES tile planes through LDS; the small-M kernels sum up to 64 planes (span
+        // planes of the 64x64 / 128x128 producers) in their epilogue
+        const bool big = gemm_uses_256(M, N);
+        const bool cons_ok = ext->ln_planes <= 0 || (lnf && ext->ln_planes <= (big ? FOLD_MAX_PLANES : 64) && ext->ln_ld >= M && ext->ln_cols > 0 &&
+                                                     (!big || (ext->ln_ld % 2) == 0));
+        if (!prod_ok || !cons_ok || (!big && ext->stats_by_tile)) {
             seedmi_set_error("seedmi_gemm_bf16_ext: statistics by tile need the 256x256 kernel for this shape (seedmi_gemm_tile_stats_supported), "
                              "an even stats_ld / ln_ld >= M, stats_out resp. ln_stats + ln_colsum + bias_f32, and ln_planes <= %d", FOLD_MAX_PLANES);
             return SEEDMI_E_SHAPE;

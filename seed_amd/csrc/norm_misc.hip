@@ -145,9 +145,7 @@ __global__ void stats_finalize_kernel(const float2* __restrict__ part, int spans
     const float2* pr = part + row;
     float s1 = 0.f, s2 = 0.f;
     for (int i = 0; i < spans; ++i) { const float2 t = pr[(size_t)i * ld]; s1 += t.x; s2 += t.y; }
-    const float mean = s1 * inv_n;
-    const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
-    out[row] = make_float2(mean, rsqrtf(var + eps));
+    out[row] = seedmi_ln_finish(s1, s2, inv_n, eps);
 }
 
 template <bool RMS, bool PACK = false>

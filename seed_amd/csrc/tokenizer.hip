@@ -198,14 +198,24 @@ int run_phase(const Part& p, int phase) {
                 e_fc1 = e_par; e_fc1.ln_colsum = (const float*)L.fc1_cs; e_fc1.bias_f32 = (const float*)L.fc1_bf;
                 if (phase > 0) { e_qkv = e_par; e_qkv.ln_colsum = (const float*)L.qkv_cs; e_qkv.bias_f32 = (const float*)L.qkv_bf; }
             }
+            // Small sub-batches (one image: M = 257): none of the block's GEMMs runs on the 256x256 kernel, and the consumers (64x64 / 128x128
+            // kernels) finish the row statistics in their own epilogue from the producers' span planes - same sums, same order, same finishing
+            // expression as the finalize kernel, so the same bits - and the two finalize launches per block disappear.
+            const bool in_consumer = !by_tile && !seedmi_gemm_tile_stats_supported((int)M, 3 * D) && !seedmi_gemm_tile_stats_supported((int)M, F) &&
+                                     !seedmi_gemm_tile_stats_supported((int)M, D) && t.spans <= 64;
+            if (in_consumer) {
+                seedmi_gemm_ext_t e_par = {t.spart, nullptr, nullptr, nullptr, 0, 0, t.spans, (int)M, D, 1e-6f};
+                e_fc1 = e_par; e_fc1.ln_colsum = (const float*)L.fc1_cs; e_fc1.bias_f32 = (const float*)L.fc1_bf;
+                if (phase > 0) { e_qkv = e_par; e_qkv.ln_colsum = (const float*)L.qkv_cs; e_qkv.bias_f32 = (const float*)L.qkv_bf; }
+            }
             CK(GEMM_R(M, 3 * D, D, t.x, D, L.qkv_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS, t.qkv, 3 * D, &e_qkv));
             CK(seedmi_attention_bf16(t.qkv, 3 * D, t.qkv + D, 3 * D, t.qkv + 2 * D, 3 * D, t.xn, D, B, H, hd, NT, NT,
                                      vit_scale, 0, 1, s));
             CK(GEMM_R(M, D, D, t.xn, D, L.proj_w, D, L.proj_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, &e_res));
-            if (!by_tile) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
+            if (!by_tile && !in_consumer) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
             CK(GEMM_R(M, F, D, t.x, D, L.fc1_wg, D, nullptr, nullptr, 0, SEEDMI_EPI_BIAS_GELU, t.h, F, &e_fc1));
             CK(GEMM_R(M, D, F, t.h, F, L.fc2_w, F, L.fc2_b, t.x, D, SEEDMI_EPI_BIAS_RESIDUAL, t.x, D, &e_res));
-            if (!by_tile && phase + 1 < w->vit_depth) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
+            if (!by_tile && !in_consumer && phase + 1 < w->vit_depth) CK(seedmi_layernorm_stats_finalize(t.spart, t.spans, (int)M, (int)M, D, 1e-6f, t.stats, s));
             return SEEDMI_OK;
         }
         CK(seedmi_layernorm_bf16(t.x, D, L.ln1_w, L.ln1_b, 1e-6f, t.xn, D, M, D, s));
