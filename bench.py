@@ -120,7 +120,7 @@ def qkv_gemm_roofline(batch):
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    for name in ("r04_pmc_qkv_gemm256.json", "r03_pmc_qkv_gemm256.json", "r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
+    for name in ("r05_pmc_qkv_gemm256.json", "r04_pmc_qkv_gemm256.json", "r03_pmc_qkv_gemm256.json", "r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if batch == 256 and os.path.exists(pmc):
             # bytes past the L2s per launch from rocprofv3 --pmc passes of this same kernel/shape (tools/pmc_qkv.sh: PMC counters

@@ -49,6 +49,11 @@ std::atomic<int> g_gemm_persist{1};  // "gemm_persist": persistent one-workgroup
 std::atomic<int> g_gemm_streamk{1};  // "gemm_streamk": stream-K tail when the caller passes a workspace
 std::atomic<int> g_gemm_prefetch_r{0};   // "gemm_prefetch_residual": residual tile touched during the K loop (measured neutral: off)
 std::atomic<int> g_gemm_residual_nt{1};  // "gemm_residual_nt": streaming stores for the BIAS_RESIDUAL output
+// "gemm_store": how the 256x256 kernel's epilogues lay a row group's 16 rows x 128 bytes (the wave's 64-column span) over its two store instructions.
+//   64: each instruction writes 64 contiguous bytes of all 16 rows (lane transposition by v_permlane16 / 32_swap; rounds 1-4)
+//  128: each instruction writes the FULL 128-byte span of 8 rows (two DPP row rotations per register): half as many cache lines touched per
+//       instruction, every line written by one instruction instead of two halves by two
+std::atomic<int> g_gemm_store{128};
 std::atomic<int> g_gemm_variant{0};  // "gemm": 0 = auto, 128 / 256 = force a kernel
 // "gemm_sched": schedule variant of the 256x256 kernel (bits: see gemm256_kernel) for the three ViT epilogues.  31 = every measured gain of
 // round 3 (epilogue-side wait, W pre-read, two LDS-DMA requests per phase with counted waits, early residual requests): bit-identical to
@@ -97,6 +102,7 @@ struct GemmParams {
     float ln_inv_cols, ln_eps;
     int prefetch_residual;      // BIAS_RESIDUAL on the 256x256 kernel: touch the residual tile during the K loop ("gemm_prefetch_residual")
     int residual_nt;            // BIAS_RESIDUAL output stores: 1 = streaming (non-temporal), 0 = ordinary ("gemm_residual_nt")
+    int store128;               // 256x256 kernel's full-span epilogues: 1 = 128 contiguous bytes of 8 rows per store instruction ("gemm_store")
     int row_group, row_extra;   // patch-embed: out_row = m + (m / row_group) * row_extra + row_extra ; res_row = m % row_group + row_extra
 };
 
@@ -158,6 +164,22 @@ SEEDMI_DEVINL bool gelu_in_table(uint32_t h) { return ((h & 0x7fffu) - (GELU_E_M
 // instruction writes 64 contiguous bytes of a row instead of four 16-byte pieces at a 32-byte stride (whole 32-byte sectors
 // instead of half sectors: -7 % on the ViT QKV GEMM).
 struct NoHook { SEEDMI_DEVINL void operator()() const {} };
+
+// Full-line stores: (a, c) = the lane's two 16-byte pieces of row li (columns 16 g .. + 7 and 16 g + 8 .. + 15 of the wave's 64-column span).
+// o1 = what the lane contributes to row (li & 7), o2 = to row 8 + (li & 7), at byte 32 g + 16 (li >> 3) of the span: lanes li < 8 keep their first
+// piece and take the first piece of row li + 8, lanes li >= 8 keep their second piece and take the second piece of row li - 8 (a rotation by 8 inside
+// every row of 16 lanes: one DPP move per register and direction, as many instructions as the permlane transposition they replace).
+typedef unsigned seedmi_u32x4 __attribute__((ext_vector_type(4)));
+SEEDMI_DEVINL void rows_to_full_lines(const unsigned (&a)[4], const unsigned (&c)[4], seedmi_u32x4& o1, seedmi_u32x4& o2) {
+    unsigned x[4], y[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        x[d] = (unsigned)__builtin_amdgcn_update_dpp((int)a[d], (int)c[d], 0x128, 0xf, 0xc, false);     // row_ror:8 into lanes 8..15
+        y[d] = (unsigned)__builtin_amdgcn_update_dpp((int)c[d], (int)a[d], 0x128, 0xf, 0x3, false);     // row_ror:8 into lanes 0..7
+    }
+    o1 = (seedmi_u32x4){x[0], x[1], x[2], x[3]};
+    o2 = (seedmi_u32x4){y[0], y[1], y[2], y[3]};
+}
 
 // producer side of the LayerNorm fold: (sum, sum of squares) of one row's 16 packed half outputs of this lane, reduced over the four
 // lanes (li + 16 g) that share the row's 64-column span; every lane of the span returns the span's totals
@@ -2122,6 +2144,10 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_sched = value;
         return SEEDMI_OK;
     }
+    if (key && !strcmp(key, "gemm_store") && (value == 64 || value == 128)) {
+        g_gemm_store = value;
+        return SEEDMI_OK;
+    }
     if (key && !strcmp(key, "gemm_small") && (value == 0 || value == 1)) {
         g_gemm_small = value;
         return SEEDMI_OK;
@@ -2280,6 +2306,7 @@ extern "C" int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda,
     p.ln_eps = p.ln_planes ? ext->ln_eps : 0.f;
     p.prefetch_residual = g_gemm_prefetch_r;
     p.residual_nt = g_gemm_residual_nt;
+    p.store128 = g_gemm_store == 128;
     p.row_group = row_group > 0 ? row_group : 1;
     p.row_extra = row_extra;
     hipStream_t s = (hipStream_t)stream;

@@ -12,15 +12,16 @@ from seed_amd import config as C, lib as L  # noqa: E402
 from seed_amd.tokenizer_engine import TokenizerEngine  # noqa: E402
 from seed_amd.weights import make_tokenizer_state_dict  # noqa: E402
 
-lib = L.load()
+DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}[os.environ.get("DTYPE", "bf16")]      # fp16: libseedmi_f16.so (the reference's shipped type)
+lib = L.load(DTYPE)
 B = int(os.environ.get("B", "256"))
 ROUNDS = int(os.environ.get("ROUNDS", "4"))
 sets = sys.argv[1:] or ["tokenize_streams=2,tokenize_streamk=1", "tokenize_streams=1,tokenize_streamk=1", "tokenize_streams=2,tokenize_streamk=0",
                         "tokenize_streams=1,tokenize_streamk=0"]
 sd = make_tokenizer_state_dict(C.SEED2, seed=0, device="cuda")
-eng = TokenizerEngine(sd, C.SEED2, device="cuda")
+eng = TokenizerEngine(sd, C.SEED2, device="cuda", dtype=DTYPE)
 del sd
-img = torch.randn(B, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)).bfloat16()
+img = torch.randn(B, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)).to(DTYPE)
 defaults = {"tokenize_streams": 2, "tokenize_streamk": 0, "gemm": 0, "gemm_sched": -1, "attn_vit": 5, "attn_xcd": 1, "attn_store_wait": 1, "gemm_group_m": 0, "gemm_prefetch_residual": 0, "gemm_residual_nt": 1, "tokenize_lnfold": 1, "tokenize_split_rounds": 0, "tokenize_vq_head": 1, "tokenize_tile_stats": 0}
 
 
@@ -30,7 +31,7 @@ def apply(spec):
     for kv in spec.split(","):
         if kv:
             k, v = kv.split("=")
-            L.check(lib.seedmi_set_option(k.encode(), int(v)), kv)
+            L.check(lib.seedmi_set_option(k.encode(), int(v)), kv, lib)
 
 
 ref = {}
