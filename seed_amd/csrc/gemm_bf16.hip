@@ -180,6 +180,31 @@ SEEDMI_DEVINL void rows_to_full_lines(const unsigned (&a)[4], const unsigned (&c
     o1 = (seedmi_u32x4){x[0], x[1], x[2], x[3]};
     o2 = (seedmi_u32x4){y[0], y[1], y[2], y[3]};
 }
+// rounds 1-4: pieces [0,2,4,6] / [1,3,5,7] of the row's eight -> permlane16_swap [0,1,4,5] / [2,3,6,7] -> permlane32_swap [0,1,2,3] / [4,5,6,7]
+SEEDMI_DEVINL void rows_to_half_lines(const unsigned (&a)[4], const unsigned (&c)[4], seedmi_u32x4& o1, seedmi_u32x4& o2) {
+    unsigned x[4], y[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const auto t1 = __builtin_amdgcn_permlane16_swap(a[d], c[d], false, false);
+        const auto t2 = __builtin_amdgcn_permlane32_swap(t1[0], t1[1], false, false);
+        x[d] = t2[0];
+        y[d] = t2[1];
+    }
+    o1 = (seedmi_u32x4){x[0], x[1], x[2], x[3]};
+    o2 = (seedmi_u32x4){y[0], y[1], y[2], y[3]};
+}
+// where the two registers of a lane go: row offsets inside the 16-row group and element columns, for either layout
+struct SpanStoreLane {
+    int r1, r2;
+    uint32_t c1, c2;
+    SEEDMI_DEVINL SpanStoreLane(bool full_lines, int nb, int li) {
+        const uint32_t wcol = (uint32_t)((nb & ~63) + 8 * ((nb >> 4) & 3));
+        r1 = full_lines ? (li & 7) : li;
+        r2 = full_lines ? (li & 7) + 8 : li;
+        c1 = full_lines ? (uint32_t)(nb + 8 * (li >> 3)) : wcol;
+        c2 = full_lines ? c1 : wcol + 32;
+    }
+};
 
 // producer side of the LayerNorm fold: (sum, sum of squares) of one row's 16 packed half outputs of this lane, reduced over the four
 // lanes (li + 16 g) that share the row's 64-column span; every lane of the span returns the span's totals
@@ -236,7 +261,6 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
         return;
     }
     const bool full = LNF || (nb + 16 <= p.N);
-    const uint32_t wcol = (uint32_t)(span0 + 8 * ((nb >> 4) & 3));    // first column of the lane's pieces after the lane transposition
     float bias[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) bias[i] = 0.f;
@@ -431,20 +455,17 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                 if (span_full) {
                     // rows of 16 lanes = column groups g: s0 = pieces [0,2,4,6], s1 = [1,3,5,7] of the row's eight 16-byte pieces;
                     // permlane16_swap -> [0,1,4,5] / [2,3,6,7]; permlane32_swap -> [0,1,2,3] / [4,5,6,7]
-                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                    unsigned a[4] = {s0.x, s0.y, s0.z, s0.w}, c[4] = {s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const auto t1 = __builtin_amdgcn_permlane16_swap(a[d], c[d], false, false);
-                        const auto t2 = __builtin_amdgcn_permlane32_swap(t1[0], t1[1], false, false);
-                        a[d] = t2[0];
-                        c[d] = t2[1];
-                    }
-                    if (m < Mend) {
-                        bf16_t* wp = p.C + ((uint32_t)out_row * (uint32_t)p.ldc + wcol);
-                        __builtin_nontemporal_store((u32x4_t){a[0], a[1], a[2], a[3]}, (u32x4_t*)wp);
-                        __builtin_nontemporal_store((u32x4_t){c[0], c[1], c[2], c[3]}, (u32x4_t*)(wp + 32));
-                    }
+                    // ("gemm_store" = 128: the full 128-byte span of 8 rows per instruction instead - rows_to_full_lines)
+                    const unsigned a[4] = {s0.x, s0.y, s0.z, s0.w}, c[4] = {s1.x, s1.y, s1.z, s1.w};
+                    seedmi_u32x4 oa, oc;
+                    // (the patch embedding maps rows - out_row != m - and keeps the lane's own row)
+                    const bool full_lines = EPI != EPI_PATCH_EMBED && p.store128 != 0;
+                    if (full_lines) rows_to_full_lines(a, c, oa, oc);
+                    else rows_to_half_lines(a, c, oa, oc);
+                    const SpanStoreLane sl(full_lines, nb, li);
+                    const int d1 = sl.r1 - li, d2 = sl.r2 - li;              // 0 / 0 for the half-line layout
+                    if (m + d1 < Mend) __builtin_nontemporal_store(oa, (seedmi_u32x4*)(p.C + ((uint32_t)(out_row + d1) * (uint32_t)p.ldc + sl.c1)));
+                    if (m + d2 < Mend) __builtin_nontemporal_store(oc, (seedmi_u32x4*)(p.C + ((uint32_t)(out_row + d2) * (uint32_t)p.ldc + sl.c2)));
                 } else if (p.skip_epilogue == 2) {                       // timing ablation: everything but the stores themselves
                     if ((s0.x ^ s1.w) == 0x12345678u) *(uint4*)cp = s0;
                 } else if (p.skip_epilogue == 3) {                // A/B: ordinary (L2-allocating) stores
@@ -481,7 +502,6 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
                                            char* stat_lds, int row_end = -1) {
     const int Mend = row_end < 0 ? p.M : row_end;
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    const uint32_t wcol = (uint32_t)((nb & ~63) + 8 * ((nb >> 4) & 3));
     float bias[16];
     {
         const uint4 b0 = p.bias ? *(const uint4*)(p.bias + nb) : make_uint4(0, 0, 0, 0);
@@ -532,27 +552,20 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
             const float2 st = row_stats(spk, 16);                  // parked in the wave's LDS slice: no register held, no store yet
             if ((nb & 48) == 0) *(float2*)(stat_lds + 8 * (16 * mi_abs + li)) = st;
         }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const auto t1 = __builtin_amdgcn_permlane16_swap(a[d], c[d], false, false);
-            const auto t2 = __builtin_amdgcn_permlane32_swap(t1[0], t1[1], false, false);
-            a[d] = t2[0];
-            c[d] = t2[1];
-        }
-        oa = (u32x4_t){a[0], a[1], a[2], a[3]};
-        oc = (u32x4_t){c[0], c[1], c[2], c[3]};
+        if (p.store128) rows_to_full_lines(a, c, oa, oc);
+        else rows_to_half_lines(a, c, oa, oc);
     };
+    const SpanStoreLane sl(p.store128 != 0, nb, li);
     auto store_row = [&](int mi_abs, const u32x4_t& oa, const u32x4_t& oc) {
-        const int m = mrow0 + 16 * mi_abs + li;
-        if (m < Mend) {
-            bf16_t* wp = p.C + ((uint32_t)m * (uint32_t)p.ldc + wcol);
-            if (p.residual_nt) {
-                __builtin_nontemporal_store(oa, (u32x4_t*)wp);
-                __builtin_nontemporal_store(oc, (u32x4_t*)(wp + 32));
-            } else {                                              // the residual stream is re-read soon: let it allocate in the caches
-                *(u32x4_t*)wp = oa;
-                *(u32x4_t*)(wp + 32) = oc;
-            }
+        const int m1 = mrow0 + 16 * mi_abs + sl.r1, m2 = mrow0 + 16 * mi_abs + sl.r2;
+        u32x4_t* w1 = (u32x4_t*)(p.C + ((uint32_t)m1 * (uint32_t)p.ldc + sl.c1));
+        u32x4_t* w2 = (u32x4_t*)(p.C + ((uint32_t)m2 * (uint32_t)p.ldc + sl.c2));
+        if (p.residual_nt) {
+            if (m1 < Mend) __builtin_nontemporal_store(oa, w1);
+            if (m2 < Mend) __builtin_nontemporal_store(oc, w2);
+        } else {                                                  // the residual stream is re-read soon: let it allocate in the caches
+            if (m1 < Mend) *w1 = oa;
+            if (m2 < Mend) *w2 = oc;
         }
     };
     u32x4_t ha[4], hc[4];
@@ -623,7 +636,6 @@ SEEDMI_DEVINL void gemm_epilogue_fold8(const GemmParams& p, f32x4 (&acc)[8][4], 
         after_loads();
         return;
     }
-    const uint32_t wcol = (uint32_t)((nb & ~63) + 8 * ((nb >> 4) & 3));
     auto finish_row = [&](int mi, u32x4_t& oa, u32x4_t& oc) {
         uint32_t pk[8];
 #pragma unroll
@@ -651,23 +663,14 @@ SEEDMI_DEVINL void gemm_epilogue_fold8(const GemmParams& p, f32x4 (&acc)[8][4], 
             }
         }
         unsigned a[4] = {pk[0], pk[1], pk[2], pk[3]}, c[4] = {pk[4], pk[5], pk[6], pk[7]};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const auto t1 = __builtin_amdgcn_permlane16_swap(a[d], c[d], false, false);
-            const auto t2 = __builtin_amdgcn_permlane32_swap(t1[0], t1[1], false, false);
-            a[d] = t2[0];
-            c[d] = t2[1];
-        }
-        oa = (u32x4_t){a[0], a[1], a[2], a[3]};
-        oc = (u32x4_t){c[0], c[1], c[2], c[3]};
+        if (p.store128) rows_to_full_lines(a, c, oa, oc);
+        else rows_to_half_lines(a, c, oa, oc);
     };
+    const SpanStoreLane sl(p.store128 != 0, nb, li);
     auto store_row = [&](int mi, const u32x4_t& oa, const u32x4_t& oc) {
-        const int m = mrow0 + 16 * mi + li;
-        if (m < Mend) {
-            bf16_t* wp = p.C + ((uint32_t)m * (uint32_t)p.ldc + wcol);
-            __builtin_nontemporal_store(oa, (u32x4_t*)wp);
-            __builtin_nontemporal_store(oc, (u32x4_t*)(wp + 32));
-        }
+        const int m1 = mrow0 + 16 * mi + sl.r1, m2 = mrow0 + 16 * mi + sl.r2;
+        if (m1 < Mend) __builtin_nontemporal_store(oa, (u32x4_t*)(p.C + ((uint32_t)m1 * (uint32_t)p.ldc + sl.c1)));
+        if (m2 < Mend) __builtin_nontemporal_store(oc, (u32x4_t*)(p.C + ((uint32_t)m2 * (uint32_t)p.ldc + sl.c2)));
     };
     u32x4_t ha[4], hc[4];
 #pragma unroll

@@ -4,7 +4,7 @@ tokenizer issues them: QKV = BIAS + LayerNorm fold, fc1 = BIAS_GELU + fold, proj
 Every variant's output (and statistics) must be BIT-IDENTICAL to schedule 0's; timing = REPS back-to-back launches per round, ROUNDS rounds
 interleaved over the variants in one process (median and min ms, TFLOP/s of the median).
 
-    SCHEDS=0,1,2,3,6,7 SHAPES=qkv,proj,fc1,fc2 B=256 python tools/gemm_sched_ab.py
+    SCHEDS=8273:64,8273:128,57425 SHAPES=qkv,proj,fc1,fc2 B=256 python tools/gemm_sched_ab.py
 """
 import ctypes
 import json
@@ -21,7 +21,13 @@ lib = L.load()
 B = int(os.environ.get("B", "256"))
 REPS = int(os.environ.get("REPS", "40"))
 ROUNDS = int(os.environ.get("ROUNDS", "5"))
-SCHEDS = [int(v) for v in os.environ.get("SCHEDS", "0,1,2,3,6,7").split(",")]
+SCHEDS = os.environ.get("SCHEDS", "0,8273,24657,57425").split(",")     # "sched" or "sched:store" (gemm_store 64 | 128, the epilogue's store layout)
+
+
+def select(arm):
+    v, _, st = arm.partition(":")
+    L.check(lib.seedmi_set_option(b"gemm_sched", int(v)), "gemm_sched")
+    L.check(lib.seedmi_set_option(b"gemm_store", int(st or 128)), "gemm_store")
 EXTRA = os.environ.get("EXTRA", "")          # further options applied to every arm, e.g. "gemm_group_m=4"
 ONLY = [x for x in os.environ.get("SHAPES", "").split(",") if x]
 OUT = os.environ.get("OUT", "gpurun_out/gemm_sched_ab.json")
@@ -60,7 +66,7 @@ for name, M, N, K, epi in SHAPES:
         aux = None
     ref_c, ref_aux, ok = None, None, {}
     for v in SCHEDS:                                       # bit-identity first (C poisoned before every variant)
-        L.check(lib.seedmi_set_option(b"gemm_sched", v), "gemm_sched")
+        select(v)
         C.fill_(float("nan"))
         if aux is not None:
             aux.fill_(float("nan"))
@@ -80,7 +86,7 @@ for name, M, N, K, epi in SHAPES:
     times = {v: [] for v in SCHEDS}
     for r in range(ROUNDS + 1):
         for v in SCHEDS:
-            lib.seedmi_set_option(b"gemm_sched", v)
+            select(v)
             run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -100,11 +106,12 @@ for name, M, N, K, epi in SHAPES:
     row = {}
     for v in SCHEDS:
         med, mn = statistics.median(times[v]), min(times[v])
-        row["sched_%d" % v] = {"median_ms": round(med, 4), "min_ms": round(mn, 4), "tflops": round(2.0 * M * N * K / med / 1e9, 1),
+        row["sched_%s" % v] = {"median_ms": round(med, 4), "min_ms": round(mn, 4), "tflops": round(2.0 * M * N * K / med / 1e9, 1),
                                "bit_identical_to_sched_0": ok[v]}
     res[name] = row
     print(name, json.dumps(row), flush=True)
     del A, W, C, ref_c, ref_aux
 lib.seedmi_set_option(b"gemm_sched", -1)
+lib.seedmi_set_option(b"gemm_store", 128)
 os.makedirs(os.path.dirname(OUT) or ".", exist_ok=True)
 json.dump(res, open(OUT, "w"), indent=1)
