@@ -160,9 +160,9 @@ SEEDMI_DEVINL bool gelu_in_table(uint32_t h) { return ((h & 0x7fffu) - (GELU_E_M
 
 // ---- shared epilogue: the lane owns rows mrow0 + 16*mi + li (mi < MT) and the 16 contiguous columns nb..nb+15
 // LANE4 (lane = li + 16 g, the four lanes of a row own adjacent 16-column groups): when the wave's whole 64-column span lies
-// inside N the 16-byte halves of the four lanes are transposed with v_permlane16_swap / v_permlane32_swap so that each store
-// instruction writes 64 contiguous bytes of a row instead of four 16-byte pieces at a 32-byte stride (whole 32-byte sectors
-// instead of half sectors: -7 % on the ViT QKV GEMM).
+// inside N the 16-byte pieces of the four lanes are exchanged so that a store instruction writes whole cache lines: rounds 1-4 64 contiguous
+// bytes of each of 16 rows (v_permlane16_swap / v_permlane32_swap; whole 32-byte sectors instead of half sectors: -7 % on the ViT QKV GEMM),
+// round 5 the full 128-byte span of 8 rows (rows_to_full_lines below: a further +1 ... 4.5 % per ViT GEMM, +2.4 % per tokenize pass).
 struct NoHook { SEEDMI_DEVINL void operator()() const {} };
 
 // Full-line stores: (a, c) = the lane's two 16-byte pieces of row li (columns 16 g .. + 7 and 16 g + 8 .. + 15 of the wave's 64-column span).
@@ -170,6 +170,13 @@ struct NoHook { SEEDMI_DEVINL void operator()() const {} };
 // piece and take the first piece of row li + 8, lanes li >= 8 keep their second piece and take the second piece of row li - 8 (a rotation by 8 inside
 // every row of 16 lanes: one DPP move per register and direction, as many instructions as the permlane transposition they replace).
 typedef unsigned seedmi_u32x4 __attribute__((ext_vector_type(4)));
+// (the product build knows only the full-line layout; the devtools build keeps rounds 1-4's half-line layout behind "gemm_store" = 64 for the A/B
+// in profiles/r05_store128_*.json)
+#ifdef SEEDMI_DEVTOOLS
+#define SEEDMI_FULL_LINES(p) ((p).store128 != 0)
+#else
+#define SEEDMI_FULL_LINES(p) true
+#endif
 SEEDMI_DEVINL void rows_to_full_lines(const unsigned (&a)[4], const unsigned (&c)[4], seedmi_u32x4& o1, seedmi_u32x4& o2) {
     unsigned x[4], y[4];
 #pragma unroll
@@ -459,7 +466,7 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                     const unsigned a[4] = {s0.x, s0.y, s0.z, s0.w}, c[4] = {s1.x, s1.y, s1.z, s1.w};
                     seedmi_u32x4 oa, oc;
                     // (the patch embedding maps rows - out_row != m - and keeps the lane's own row)
-                    const bool full_lines = EPI != EPI_PATCH_EMBED && p.store128 != 0;
+                    const bool full_lines = EPI != EPI_PATCH_EMBED && SEEDMI_FULL_LINES(p);
                     if (full_lines) rows_to_full_lines(a, c, oa, oc);
                     else rows_to_half_lines(a, c, oa, oc);
                     const SpanStoreLane sl(full_lines, nb, li);
@@ -530,7 +537,7 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
             r2[EARLY ? mi : 0][1] = *(const uint4*)(rp + 8);
         }
     };
-    // finished row (packed, lane-transposed so that a store instruction writes 64 contiguous bytes of a row)
+    // finished row (packed, lanes exchanged so that a store instruction writes the full 128-byte span of 8 rows)
     auto finish_row = [&](int mi_abs, int mi_rr, u32x4_t& oa, u32x4_t& oc) {
         const uint4 r0 = (EARLY && mi_abs >= 4) ? r2[EARLY ? mi_rr : 0][0] : rr[mi_rr][0];
         const uint4 r1 = (EARLY && mi_abs >= 4) ? r2[EARLY ? mi_rr : 0][1] : rr[mi_rr][1];
@@ -552,10 +559,10 @@ SEEDMI_DEVINL void gemm_epilogue_residual8(const GemmParams& p, f32x4 (&acc)[8][
             const float2 st = row_stats(spk, 16);                  // parked in the wave's LDS slice: no register held, no store yet
             if ((nb & 48) == 0) *(float2*)(stat_lds + 8 * (16 * mi_abs + li)) = st;
         }
-        if (p.store128) rows_to_full_lines(a, c, oa, oc);
+        if (SEEDMI_FULL_LINES(p)) rows_to_full_lines(a, c, oa, oc);
         else rows_to_half_lines(a, c, oa, oc);
     };
-    const SpanStoreLane sl(p.store128 != 0, nb, li);
+    const SpanStoreLane sl(SEEDMI_FULL_LINES(p), nb, li);
     auto store_row = [&](int mi_abs, const u32x4_t& oa, const u32x4_t& oc) {
         const int m1 = mrow0 + 16 * mi_abs + sl.r1, m2 = mrow0 + 16 * mi_abs + sl.r2;
         u32x4_t* w1 = (u32x4_t*)(p.C + ((uint32_t)m1 * (uint32_t)p.ldc + sl.c1));
@@ -663,10 +670,10 @@ SEEDMI_DEVINL void gemm_epilogue_fold8(const GemmParams& p, f32x4 (&acc)[8][4], 
             }
         }
         unsigned a[4] = {pk[0], pk[1], pk[2], pk[3]}, c[4] = {pk[4], pk[5], pk[6], pk[7]};
-        if (p.store128) rows_to_full_lines(a, c, oa, oc);
+        if (SEEDMI_FULL_LINES(p)) rows_to_full_lines(a, c, oa, oc);
         else rows_to_half_lines(a, c, oa, oc);
     };
-    const SpanStoreLane sl(p.store128 != 0, nb, li);
+    const SpanStoreLane sl(SEEDMI_FULL_LINES(p), nb, li);
     auto store_row = [&](int mi, const u32x4_t& oa, const u32x4_t& oc) {
         const int m1 = mrow0 + 16 * mi + sl.r1, m2 = mrow0 + 16 * mi + sl.r2;
         if (m1 < Mend) __builtin_nontemporal_store(oa, (u32x4_t*)(p.C + ((uint32_t)m1 * (uint32_t)p.ldc + sl.c1)));
@@ -2147,10 +2154,12 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_sched = value;
         return SEEDMI_OK;
     }
+#ifdef SEEDMI_DEVTOOLS
     if (key && !strcmp(key, "gemm_store") && (value == 64 || value == 128)) {
         g_gemm_store = value;
         return SEEDMI_OK;
     }
+#endif
     if (key && !strcmp(key, "gemm_small") && (value == 0 || value == 1)) {
         g_gemm_small = value;
         return SEEDMI_OK;

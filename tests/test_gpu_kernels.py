@@ -69,20 +69,18 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[64, 65, 128, 256, (256, 0), (256, 24657), (256, 57425), (256, -1, 64)],
-                ids=["gemm64", "gemm64_4wave", "gemm128", "gemm256", "gemm256_sched0", "gemm256_seam", "gemm256_peel", "gemm256_store64"])
+@pytest.fixture(params=[64, 65, 128, 256, (256, 0), (256, 24657), (256, 57425)],
+                ids=["gemm64", "gemm64_4wave", "gemm128", "gemm256", "gemm256_sched0", "gemm256_seam", "gemm256_peel"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (64x64 deep-ring small-M kernel, 128x128 two-barrier and 256x256 staggered deep pipeline), the 256x256 kernel
     under its default schedule (gemm_sched 8273: two-phase K-tile, position-free body, round 4), under the round-2 schedule (0) and
     under round 5's seam (24657) and seam + peeled store-tolerant K-tiles (57425) - the values the product library keeps selectable."""
-    variant, sched, store = (tuple(request.param) + (128,))[:3] if isinstance(request.param, tuple) else (request.param, -1, 128)
+    variant, sched = request.param if isinstance(request.param, tuple) else (request.param, -1)
     L.check(lib.seedmi_set_option(b"gemm", variant), "set_option")
     L.check(lib.seedmi_set_option(b"gemm_sched", sched), "set_option")
-    L.check(lib.seedmi_set_option(b"gemm_store", store), "set_option")      # 64: rounds 1-4's half-line store layout of the epilogues
     yield variant
     lib.seedmi_set_option(b"gemm", 0)
     lib.seedmi_set_option(b"gemm_sched", -1)
-    lib.seedmi_set_option(b"gemm_store", 128)
 
 
 GEMM_SHAPES = [

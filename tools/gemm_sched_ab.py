@@ -24,10 +24,21 @@ ROUNDS = int(os.environ.get("ROUNDS", "5"))
 SCHEDS = os.environ.get("SCHEDS", "0,8273,24657,57425").split(",")     # "sched" or "sched:store" (gemm_store 64 | 128, the epilogue's store layout)
 
 
+# LIBS="v0=seed_amd/libseedmi_v0.so,v2=seed_amd/libseedmi.so": A/B builds of the library in one process, arms "v0@8273", "v2@8273"
+LIBS = {"": lib}
+for kv in filter(None, os.environ.get("LIBS", "").split(",")):
+    k, _, path = kv.partition("=")
+    LIBS[k] = L._load_path(os.path.abspath(path), 0)
+
+
 def select(arm):
+    global lib
+    name, _, arm = arm.rpartition("@")
+    lib = LIBS[name]
     v, _, st = arm.partition(":")
     L.check(lib.seedmi_set_option(b"gemm_sched", int(v)), "gemm_sched")
-    L.check(lib.seedmi_set_option(b"gemm_store", int(st or 128)), "gemm_store")
+    if st:                                                          # (SEEDMI_LIB_PATH=seed_amd/libseedmi_dev.so: the devtools build knows the key)
+        L.check(lib.seedmi_set_option(b"gemm_store", int(st)), "gemm_store")
 EXTRA = os.environ.get("EXTRA", "")          # further options applied to every arm, e.g. "gemm_group_m=4"
 ONLY = [x for x in os.environ.get("SHAPES", "").split(",") if x]
 OUT = os.environ.get("OUT", "gpurun_out/gemm_sched_ab.json")
