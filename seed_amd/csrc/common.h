@@ -53,6 +53,23 @@ SEEDMI_DEVINL float lo_bf(uint32_t u) { return __uint_as_float(u << 16); }
 SEEDMI_DEVINL float hi_bf(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 SEEDMI_DEVINL f32x4 seedmi_mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 #endif
+
+// Full-line stores: (a, c) = the lane's two 16-byte pieces of row li (columns 16 g .. + 7 and 16 g + 8 .. + 15 of the wave's 64-column span).
+// o1 = what the lane contributes to row (li & 7), o2 = to row 8 + (li & 7), at byte 32 g + 16 (li >> 3) of the span: lanes li < 8 keep their first
+// piece and take the first piece of row li + 8, lanes li >= 8 keep their second piece and take the second piece of row li - 8 (a rotation by 8 inside
+// every row of 16 lanes: one DPP move per register and direction, as many instructions as the permlane transposition they replace).
+typedef unsigned seedmi_u32x4 __attribute__((ext_vector_type(4)));
+SEEDMI_DEVINL void rows_to_full_lines(const unsigned (&a)[4], const unsigned (&c)[4], seedmi_u32x4& o1, seedmi_u32x4& o2) {
+    unsigned x[4], y[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        x[d] = (unsigned)__builtin_amdgcn_update_dpp((int)a[d], (int)c[d], 0x128, 0xf, 0xc, false);     // row_ror:8 into lanes 8..15
+        y[d] = (unsigned)__builtin_amdgcn_update_dpp((int)c[d], (int)a[d], 0x128, 0xf, 0x3, false);     // row_ror:8 into lanes 0..7
+    }
+    o1 = (seedmi_u32x4){x[0], x[1], x[2], x[3]};
+    o2 = (seedmi_u32x4){y[0], y[1], y[2], y[3]};
+}
+
 // value rounded to the 16-bit element and widened again: the point where the reference materialises a half tensor
 SEEDMI_DEVINL float rbf(float f) { return bf2f(f2bf(f)); }
 

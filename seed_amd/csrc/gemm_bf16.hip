@@ -165,11 +165,6 @@ SEEDMI_DEVINL bool gelu_in_table(uint32_t h) { return ((h & 0x7fffu) - (GELU_E_M
 // round 5 the full 128-byte span of 8 rows (rows_to_full_lines below: a further +1 ... 4.5 % per ViT GEMM, +2.4 % per tokenize pass).
 struct NoHook { SEEDMI_DEVINL void operator()() const {} };
 
-// Full-line stores: (a, c) = the lane's two 16-byte pieces of row li (columns 16 g .. + 7 and 16 g + 8 .. + 15 of the wave's 64-column span).
-// o1 = what the lane contributes to row (li & 7), o2 = to row 8 + (li & 7), at byte 32 g + 16 (li >> 3) of the span: lanes li < 8 keep their first
-// piece and take the first piece of row li + 8, lanes li >= 8 keep their second piece and take the second piece of row li - 8 (a rotation by 8 inside
-// every row of 16 lanes: one DPP move per register and direction, as many instructions as the permlane transposition they replace).
-typedef unsigned seedmi_u32x4 __attribute__((ext_vector_type(4)));
 // (the product build knows only the full-line layout; the devtools build keeps rounds 1-4's half-line layout behind "gemm_store" = 64 for the A/B
 // in profiles/r05_store128_*.json)
 #ifdef SEEDMI_DEVTOOLS
@@ -177,16 +172,6 @@ typedef unsigned seedmi_u32x4 __attribute__((ext_vector_type(4)));
 #else
 #define SEEDMI_FULL_LINES(p) true
 #endif
-SEEDMI_DEVINL void rows_to_full_lines(const unsigned (&a)[4], const unsigned (&c)[4], seedmi_u32x4& o1, seedmi_u32x4& o2) {
-    unsigned x[4], y[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        x[d] = (unsigned)__builtin_amdgcn_update_dpp((int)a[d], (int)c[d], 0x128, 0xf, 0xc, false);     // row_ror:8 into lanes 8..15
-        y[d] = (unsigned)__builtin_amdgcn_update_dpp((int)c[d], (int)a[d], 0x128, 0xf, 0x3, false);     // row_ror:8 into lanes 0..7
-    }
-    o1 = (seedmi_u32x4){x[0], x[1], x[2], x[3]};
-    o2 = (seedmi_u32x4){y[0], y[1], y[2], y[3]};
-}
 // rounds 1-4: pieces [0,2,4,6] / [1,3,5,7] of the row's eight -> permlane16_swap [0,1,4,5] / [2,3,6,7] -> permlane32_swap [0,1,2,3] / [4,5,6,7]
 SEEDMI_DEVINL void rows_to_half_lines(const unsigned (&a)[4], const unsigned (&c)[4], seedmi_u32x4& o1, seedmi_u32x4& o2) {
     unsigned x[4], y[4];
