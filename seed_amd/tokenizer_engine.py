@@ -206,6 +206,10 @@ class TokenizerEngine:
             images = images.float()
         images = images.contiguous()
         B = images.shape[0]
+        if B == 0:
+            # an empty batch is a valid input of the reference (every module maps over dim 0: get_codebook_indices returns [0, 32]) and what a
+            # rank with an empty shard passes (dist.tokenize_data_parallel with fewer images than ranks): no launch, no workspace
+            return torch.empty(0, cfg.n_query, dtype=torch.int64, device=self.device)
         if B > self.max_batch and taps is None:
             # one C call addresses its matrices with 32-bit element offsets (B * n_tokens * ffn < 2^31): larger batches are a
             # sequence of calls on the same stream (the batch is a pure map over images)

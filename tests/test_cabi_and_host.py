@@ -188,6 +188,12 @@ def fake_encode(x):                                            # stands in for T
     return (x.flatten(1).sum(1, keepdim=True) * 1000).long() + torch.arange(32)[None]
 ids = tokenize_data_parallel(fake_encode, images, dist)
 assert ids.shape == (7, 32) and torch.equal(ids, fake_encode(images)), "DP result differs from single-process result"
+# fewer images than ranks: rank 1's shard is EMPTY (its encode call sees a [0, 3, 4, 4] batch and returns [0, 32]) and the gather still
+# hands every rank the one image's ids; an empty global batch gathers to [0, 32]
+one = tokenize_data_parallel(fake_encode, images[:1], dist)
+assert one.shape == (1, 32) and torch.equal(one, fake_encode(images[:1]))
+none = tokenize_data_parallel(fake_encode, images[:0], dist)
+assert none.shape == (0, 32) and none.dtype == torch.int64
 eq = gather_token_ids(torch.full((4, 32), rank, dtype=torch.int64), dist)
 assert eq.shape == (8, 32) and (eq[:4] == 0).all() and (eq[4:] == 1).all()
 # the wire format is int16 (ids < 8192), widened back to the caller's int64 on arrival; the extremes of the codebook range survive it,

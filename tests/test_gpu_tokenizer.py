@@ -269,6 +269,11 @@ def test_batch_independence_and_raggedness():
     singles = torch.cat([eng.encode(img[i:i + 1]) for i in range(5)], 0)
     assert torch.equal(ids, singles)
     assert torch.equal(eng.encode(img[1:4]), ids[1:4])
+    # the empty batch (a rank whose shard is empty, or a caller mapping over no images): [0, n_query] int64 on the device, as the reference's
+    # modules return for a zero-length dim 0 - no launch, no workspace; a 3-d image is one image (seed_llama_tokenizer.py:81-82)
+    none = eng.encode(img[:0])
+    assert none.shape == (0, cfg.n_query) and none.dtype == torch.int64 and none.device == img.device
+    assert torch.equal(eng.encode(img[2]), ids[2:3])
 
 
 def test_full_size_batch256_properties():
