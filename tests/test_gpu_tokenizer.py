@@ -274,6 +274,9 @@ def test_batch_independence_and_raggedness():
     none = eng.encode(img[:0])
     assert none.shape == (0, cfg.n_query) and none.dtype == torch.int64 and none.device == img.device
     assert torch.equal(eng.encode(img[2]), ids[2:3])
+    # batches beyond one C call's 32-bit element range (max_batch: 1024 images at full size) are a sequence of calls on the same stream
+    eng.max_batch = 2
+    assert torch.equal(eng.encode(img), ids)
 
 
 def test_full_size_batch256_properties():
