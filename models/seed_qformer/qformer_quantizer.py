@@ -77,12 +77,13 @@ class Blip2QformerQuantizer:
         if dtype != self._compute_dtype:
             self._compute_dtype = dtype
             self._engine = None
+            self._detok = None
 
     def half(self):
         """The reference's shipped setting (configs/tokenizer/seed_llama_tokenizer_hf.yaml:3 `fp16: True`, seed_llama_tokenizer.py:58-59):
         the encode path then runs through libseedmi_f16.so - the same kernels and rounding places with IEEE fp16 as the 16-bit element
-        (round 5; until then .half() only warned and kept bf16).  The de-tokenizer front half still computes in bf16 and hands its result
-        over in fp16."""
+        (round 5; until then .half() only warned and kept bf16).  The de-tokenizer front half follows (seed_llama_tokenizer.py:62-63
+        .half()s it too)."""
         self._set_compute(torch.float16)
         self._out_dtype = torch.float16               # get_codebook_entry feeds an fp16 diffusers pipeline (:309-338)
         return self
@@ -128,10 +129,10 @@ class Blip2QformerQuantizer:
             if self._state_dict is None or not has_detokenizer_weights(self._state_dict):
                 raise RuntimeError("this checkpoint carries no de-tokenizer weights (blocks_image / image_down / "
                                    "distill_image_proj)")
-            self._detok = DetokenizerEngine(self._state_dict, self.cfg, device=self._device)     # raises without a GPU
+            self._detok = DetokenizerEngine(self._state_dict, self.cfg, device=self._device, dtype=self._compute_dtype)     # raises without a GPU
         return self._detok
 
     def get_codebook_entry(self, indices):
-        """qformer_quantizer.py:309-338 (use_qformer_image=False): ids [B,32] -> image embeds [B,1024] in the dtype last asked for with .half()/.bfloat16()/.float() (computed in bf16)."""
+        """qformer_quantizer.py:309-338 (use_qformer_image=False): ids [B,32] -> image embeds [B,1024] in the dtype last asked for with .half() / .bfloat16() / .float() (computed in fp16 after .half(), in bf16 otherwise)."""
         with torch.no_grad():
             return self.detokenizer.codebook_entry(indices).to(self._out_dtype)

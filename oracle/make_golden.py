@@ -222,6 +222,22 @@ def detok_golden(name, cfg, batch, seed_w, seed_ids, ref):
     print("detok", name, "embeds[0,:4]", out32[0, :4].tolist(), "bf16 rel", ((out16.float() - out32).norm() / out32.norm()).item())
 
 
+def detok_golden_fp16(name, cfg, batch, seed_w, seed_ids, ref):
+    """The same ids and weights as detok_golden through the reference's sub-modules .half()'ed (seed_llama_tokenizer.py:62-63: the shipped
+    setting), natively in fp16 on the CPU."""
+    sd = make_detokenizer_state_dict(cfg, seed=seed_w)
+    mods = ref_shims.build_reference_detokenizer_modules(ref, cfg)
+    mods.load_state_dict(sd, strict=True)
+    gen = torch.Generator().manual_seed(seed_ids)
+    ids = torch.randint(0, cfg.n_embed, (batch, cfg.n_query), generator=gen)
+    out32, _ = ref_shims.reference_get_codebook_entry(mods, ids)
+    out16, hid16 = ref_shims.reference_get_codebook_entry(mods.half(), ids)
+    assert out16.dtype == torch.float16
+    np.savez_compressed(os.path.join(GOLDEN, f"detok_{name}_fp16.npz"), seed_w=seed_w, ids=ids.numpy(),
+                        embeds_fp16=out16.float().numpy(), hidden_fp16_slice=hid16[:, :4, :64].float().numpy())
+    print("detok fp16", name, "rel vs fp32", ((out16.float() - out32).norm() / out32.norm()).item())
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -232,6 +248,8 @@ def main():
     llama_golden(ref)
     detok_golden("tiny", C.TINY, 3, 11, 5, ref)
     detok_golden("full", C.SEED2, 2, 12, 6, ref)
+    detok_golden_fp16("tiny", C.TINY, 3, 11, 5, ref)
+    detok_golden_fp16("full", C.SEED2, 2, 12, 6, ref)
     tokenizer_golden_full(ref)
     tokenizer_golden_fp16("tiny", C.TINY, 3, 0, 1234, ref)
     tokenizer_golden_fp16("mid", C.MID, 2, 1, 4321, ref)

@@ -2,7 +2,7 @@
 
 Mirrors Blip2QformerQuantizer.get_codebook_entry for use_qformer_image=False
 (models/seed_qformer/qformer_quantizer.py:309-338).  The state dict (reference key names) is repacked
-once: bf16, codebook and the two 32-wide ``decode_task_layer`` Linears zero padded to the GEMM's K granularity of 64.
+once: the engine's 16-bit element (bf16 or fp16), codebook and the two 32-wide ``decode_task_layer`` Linears zero padded to the GEMM's K granularity of 64.
 There is no CPU path: construction raises without a gfx950 device.
 """
 import ctypes as C
@@ -22,8 +22,13 @@ def has_detokenizer_weights(sd: Dict[str, torch.Tensor]) -> bool:
 
 
 class DetokenizerEngine:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: TokenizerConfig, device="cuda"):
-        self.lib = L.load()
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: TokenizerConfig, device="cuda", dtype: torch.dtype = torch.bfloat16):
+        # dtype: the 16-bit element the path computes in and returns - torch.bfloat16 (libseedmi.so) or torch.float16 (libseedmi_f16.so, the
+        # reference's shipped setting: the de-tokenizer modules are .half()'ed, seed_llama_tokenizer.py:62-63)
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise L.SeedmiError(f"DetokenizerEngine computes in bfloat16 or float16, not {dtype}")
+        self.dtype = dtype
+        self.lib = L.load(dtype)
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -31,7 +36,7 @@ class DetokenizerEngine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(self.device):
-            L.check(self.lib.seedmi_check_device(), "seedmi_check_device")
+            L.check(self.lib.seedmi_check_device(), "seedmi_check_device", self.lib)
         missing = [k for k in DETOK_KEYS if k not in state_dict]
         if missing:
             raise KeyError(f"state dict has no de-tokenizer weights (missing {missing})")
@@ -41,7 +46,7 @@ class DetokenizerEngine:
         self._pack(state_dict)
 
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
-        t = t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+        t = t.detach().to(device=self.device, dtype=self.dtype).contiguous()
         self._keep.append(t)
         return t
 
@@ -97,7 +102,7 @@ class DetokenizerEngine:
 
     def codebook_entry(self, indices: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         """indices int64 [B, n_query] (or [n_query]) on this engine's device, values in [0, n_embed).
-        Returns bf16 [B, image_features_dim] on the same device (stream ordered, no host sync)."""
+        Returns [B, image_features_dim] in the engine's dtype on the same device (stream ordered, no host sync)."""
         cfg = self.cfg
         if indices.dim() == 1:
             indices = indices.unsqueeze(0)
@@ -107,14 +112,14 @@ class DetokenizerEngine:
             raise L.SeedmiError(f"indices on {indices.device}, engine on {self.device}")
         ids = indices.to(torch.int64).contiguous()
         B = ids.shape[0]
-        out = torch.empty(B, cfg.image_features_dim, dtype=torch.bfloat16, device=self.device)
+        out = torch.empty(B, cfg.image_features_dim, dtype=self.dtype, device=self.device)
         hid = None
         if taps is not None:
-            hid = torch.empty(B * cfg.n_query, cfg.qf_dim, dtype=torch.bfloat16, device=self.device)
+            hid = torch.empty(B * cfg.n_query, cfg.qf_dim, dtype=self.dtype, device=self.device)
             taps["hidden"] = hid.view(B, cfg.n_query, -1)
         ws = self._workspace(B)
         with torch.cuda.device(self.device):
             rc = self.lib.seedmi_detokenize(C.byref(self.w), L.ptr(ids), B, L.ptr(out), L.ptr(hid), L.ptr(ws), ws.numel(),
                                             L.stream_ptr())
-        L.check(rc, "seedmi_detokenize")
+        L.check(rc, "seedmi_detokenize", self.lib)
         return out

@@ -48,6 +48,21 @@ def test_oracle_bf16_tracks_reference_bf16(golden_dir, name, cfg):
     assert e_ref < 1e-2 and e_ref < e_32, (e_ref, e_32)
 
 
+@pytest.mark.parametrize("name,cfg", CASES)
+def test_oracle_fp16_tracks_reference_fp16(golden_dir, name, cfg):
+    """The reference's shipped setting: the de-tokenizer modules .half()'ed (seed_llama_tokenizer.py:62-63).  The restatement in Prec("fp16")
+    against the reference modules run natively in fp16 (tests/golden/detok_*_fp16.npz, oracle/make_golden.py::detok_golden_fp16)."""
+    g, sd, ids = _case(golden_dir, name, cfg)
+    g16 = np.load(os.path.join(golden_dir, f"detok_{name}_fp16.npz"))
+    assert np.array_equal(g16["ids"], g["ids"]) and int(g16["seed_w"]) == int(g["seed_w"])
+    taps = {}
+    out = O.get_codebook_entry(sd, ids, cfg, "fp16", taps)
+    e_ref = _rel(out, g16["embeds_fp16"])
+    e_32 = _rel(g16["embeds_fp16"], g["embeds_fp32"])  # the reference's own fp16 error
+    assert e_ref < 2e-3 and e_ref < 1.5 * e_32, (e_ref, e_32)
+    assert _rel(taps["hidden"][:, :4, :64], g16["hidden_fp16_slice"]) < 2e-3
+
+
 def test_state_dict_has_reference_key_names():
     sd = make_detokenizer_state_dict(C.TINY)
     for k in ("quantize.embedding.weight", "decode_task_layer.0.weight", "decode_task_layer.2.bias", "pos_embed_image",
@@ -107,6 +122,31 @@ def test_detokenize_batch_is_a_pure_map_and_edge_shapes(golden_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg", CASES)
+def test_detokenize_fp16_matches_fp16_oracle_and_reference_golden(golden_dir, name, cfg):
+    """The fp16 build (libseedmi_f16.so) of the same path against the fp16 oracle and the reference modules' native-fp16 run."""
+    from seed_amd.detokenizer_engine import DetokenizerEngine
+    g, sd, ids = _case(golden_dir, name, cfg)
+    g16 = np.load(os.path.join(golden_dir, f"detok_{name}_fp16.npz"))
+    eng = DetokenizerEngine(sd, cfg, device="cuda", dtype=torch.float16)
+    taps = {}
+    out = eng.codebook_entry(ids.cuda(), taps)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float16 and tuple(out.shape) == (ids.shape[0], cfg.image_features_dim)
+    o_taps = {}
+    ref16 = O.get_codebook_entry(sd, ids, cfg, "fp16", o_taps)
+    e_oracle, e_hidden = _rel(out.float(), ref16), _rel(taps["hidden"].float(), o_taps["hidden"])
+    e_gold = _rel(out.float(), g16["embeds_fp16"])
+    e_fp32, e_ref_fp16 = _rel(out.float(), g["embeds_fp32"]), _rel(g16["embeds_fp16"], g["embeds_fp32"])
+    print(f"[detok fp16 {name}] vs fp16 oracle {e_oracle:.2e} (hidden {e_hidden:.2e}), vs reference fp16 run {e_gold:.2e}, "
+          f"vs fp32 {e_fp32:.2e} (reference fp16 vs fp32 {e_ref_fp16:.2e})")
+    assert e_hidden < 2e-3 and e_oracle < 2e-3, (e_hidden, e_oracle)
+    assert e_fp32 < 1.5 * e_ref_fp16 + 2e-4, (e_fp32, e_ref_fp16)
+    # 8x closer to fp32 than the bf16 build's bound: the point of the fp16 build
+    assert e_fp32 < 0.25 * _rel(g["embeds_bf16"], g["embeds_fp32"])
+
+
+@pytest.mark.gpu
 def test_relu_epilogue_and_dropin_surface(golden_dir):
     """image_down's bias-free Linear+ReLU epilogue on its own, and the reference-shaped call surface
     (Blip2QformerQuantizer.get_codebook_entry, ImageTokenizer.decode_embeds / decode)."""
@@ -130,4 +170,7 @@ def test_relu_epilogue_and_dropin_surface(golden_dir):
     ids = torch.randint(0, cfg.n_embed, (2, cfg.n_query)).cuda()
     emb = model.get_codebook_entry(ids)
     assert tuple(emb.shape) == (2, cfg.image_features_dim)
-    assert _rel(emb.float(), O.get_codebook_entry(sd, ids.cpu(), cfg, "bf16")) < 6e-3
+    assert emb.dtype == torch.float16                    # .half(): the fp16 build computes it (round 5)
+    assert _rel(emb.float(), O.get_codebook_entry(sd, ids.cpu(), cfg, "fp16")) < 2e-3
+    emb_bf = model.bfloat16().get_codebook_entry(ids)
+    assert emb_bf.dtype == torch.bfloat16 and _rel(emb_bf.float(), O.get_codebook_entry(sd, ids.cpu(), cfg, "bf16")) < 6e-3
