@@ -38,9 +38,10 @@ class DevicePreprocessor:
                  std=CLIP_STD, device="cuda", out_dtype=torch.float32):
         if interpolation not in (BILINEAR, BICUBIC):
             raise ValueError("interpolation must be 2 (PIL bilinear) or 3 (PIL bicubic)")
-        if out_dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("out_dtype must be float32 or bfloat16")
-        self.lib = L.load()
+        if out_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("out_dtype must be float32, bfloat16 or float16")
+        # the 16-bit output is the loaded build's element: float16 comes from libseedmi_f16.so (fp32 output is the same from either build)
+        self.lib = L.load(torch.float16 if out_dtype == torch.float16 else None)
         self.size, self.filter, self.keep_ratio = image_size, interpolation, keep_ratio
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -73,8 +74,8 @@ class DevicePreprocessor:
         if out is None:
             out = torch.empty(3, S, S, dtype=self.out_dtype, device=self.device)
         elif tuple(out.shape) != (3, S, S) or out.device != self.device or not out.is_contiguous() or \
-                out.dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("out must be a contiguous [3,S,S] float32/bfloat16 tensor on this device")
+                out.dtype not in (torch.float32, self.out_dtype):
+            raise ValueError(f"out must be a contiguous [3,S,S] float32 or {self.out_dtype} tensor on this device")
         u8 = torch.empty(S, S, 3, dtype=torch.uint8, device=self.device) if tap_u8 else None
         need = self.lib.seedmi_preprocess_workspace_bytes(h, w, rh, rw, self.filter)
         if self._ws is None or self._ws.numel() < need:
@@ -83,7 +84,7 @@ class DevicePreprocessor:
             rc = self.lib.seedmi_preprocess_image_u8(L.ptr(src), h, w, 3 * w, rh, rw, self.filter, top, left, S, S, self._mean,
                                                      self._std, L.ptr(out), 1 if out.dtype == torch.float32 else 0, L.ptr(u8),
                                                      L.ptr(self._ws), self._ws.numel(), L.stream_ptr())
-        L.check(rc, "seedmi_preprocess_image_u8")
+        L.check(rc, "seedmi_preprocess_image_u8", self.lib)
         return (out, u8) if tap_u8 else out
 
     def batch(self, images) -> torch.Tensor:

@@ -100,6 +100,9 @@ def main(argv=None):
     ap.add_argument("--gpu-preprocess", action="store_true",
                     help="resize/normalise on the device (seedmi_preprocess_image_u8, bit-exact with the PIL path); "
                          "only the JPEG decode stays on the host")
+    ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
+                    help="compute type of the tokenizer: bf16 (libseedmi.so, BASELINE.json) or fp16 (libseedmi_f16.so: what the reference tool gets from its "
+                         "tokenizer yaml's `fp16: True`, extract_image_ids_to_torchdata_parallel.py:92-93)")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,7 +114,7 @@ def main(argv=None):
     from seed_amd.tokenizer_engine import TokenizerEngine
     from seed_amd.weights import make_tokenizer_state_dict
     sd = torch.load(args.weights, map_location="cpu") if args.weights else make_tokenizer_state_dict(C.SEED2, seed=0, device="cuda")
-    eng = TokenizerEngine(sd, C.SEED2, device=f"cuda:{local}")
+    eng = TokenizerEngine(sd, C.SEED2, device=f"cuda:{local}", dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16)
     if args.images.startswith("synthetic:"):
         n = int(args.images.split(":")[1])
         items = list(range(n))

@@ -118,5 +118,7 @@ def test_device_preprocess_batch_pil_input_and_bf16():
         assert torch.equal(batch[i].cpu(), _torch_pipeline(a, 224, 3, False)[0])
     half = DevicePreprocessor(224, interpolation=3, out_dtype=torch.bfloat16)(imgs[0])
     assert torch.equal(half.cpu(), _torch_pipeline(imgs[0], 224, 3, False)[0].bfloat16())   # one rounding of the same fp32
+    h16 = DevicePreprocessor(224, interpolation=3, out_dtype=torch.float16)(imgs[0])        # the fp16 build: img.half() of the reference (:86-87)
+    assert h16.dtype == torch.float16 and torch.equal(h16.cpu(), _torch_pipeline(imgs[0], 224, 3, False)[0].half())
     with pytest.raises(ValueError):
         pre(np.zeros((4, 4), dtype=np.uint8))
