@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefill14b", action="store_true", help="(default since round 4; kept so old command lines still parse)")
     ap.add_argument("--no-prefill14b", action="store_true", help="skip the SEED-LLaMA-14B prefill leg (config 5; ~1 min)")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-build tokenize leg (extra.tokenize_fp16; ~5 s)")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--decode-batch", type=int, default=32)
     ap.add_argument("--decode-new", type=int, default=128)
@@ -260,6 +261,32 @@ def vq_argmin_leg(images=128, pass_ms=None):
     if pass_ms:
         out["share_of_pass"] = round(2 * f_ms / pass_ms, 5)                # two sub-batch launches per 256-image pass
     return out
+
+
+def tokenize_fp16_leg(cfg, device, images_bf16, codebook, ids_bf16, steps=3):
+    """The same step through the fp16 build (libseedmi_f16.so: the reference's shipped `fp16: True`; same kernels, IEEE fp16 as the 16-bit
+    element, fc1's GELU arithmetic instead of the bf16 table): images/s beside the headline bf16 number, and how many of the ids of the same
+    images (same weights, same codebook) equal the bf16 build's.  Reported, not the headline: BASELINE.json's dtype is bf16."""
+    from seed_amd.tokenizer_engine import TokenizerEngine
+    from seed_amd.weights import make_tokenizer_state_dict
+    sd = make_tokenizer_state_dict(cfg, seed=0, device="cuda")
+    eng = TokenizerEngine(sd, cfg, device=device, dtype=torch.float16)
+    del sd
+    eng.set_codebook(codebook)
+    img = images_bf16.to(torch.float16)                     # (bf16 values are fp16 values here: |x| < 8, 8 mantissa bits)
+    ids = eng.encode(img)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        ids = eng.encode(img)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"build": "libseedmi_f16.so (-DSEEDMI_F16 of the same sources)", "dtype": "f16", "value": round(img.shape[0] / ms * 1e3, 1),
+            "unit": "images/s", "ms_per_step": round(ms, 3), "steps": steps,
+            "ids_equal_to_bf16_build": round(float((ids == ids_bf16).float().mean()), 4),
+            "note": "agreement with the REFERENCE's own fp16 run on the golden images: profiles/r05_id_agreement_fp16.json (0.990; the bf16 build 0.930)"}
 
 
 def tokenize_latency_b1(eng, reps=50):
@@ -531,7 +558,8 @@ def main():
     calib = torch.randn(8, 3, 224, 224, device="cuda", generator=gc).bfloat16()
     taps = {}
     eng.encode(calib, taps)
-    eng.set_codebook(calibrate_codebook(taps["z"].float().cpu(), cfg.n_embed, seed=7))
+    codebook = calibrate_codebook(taps["z"].float().cpu(), cfg.n_embed, seed=7)
+    eng.set_codebook(codebook)
     del taps, calib
 
     # per-step events on the compute stream (asynchronous: nothing waits on them inside the timed region): tokenize time and gather time of
@@ -603,6 +631,11 @@ def main():
             extra["latency_b1"] = {"tokenize": tokenize_latency_b1(eng)}
         except Exception as e:
             extra["latency_b1"] = {"tokenize": {"error": repr(e)[:200]}}
+        if world == 1 and not args.no_fp16:
+            try:
+                extra["tokenize_fp16"] = tokenize_fp16_leg(cfg, f"cuda:{local}", images, codebook, ids[:B])
+            except Exception as e:
+                extra["tokenize_fp16"] = {"error": repr(e)[:200]}
         out["roofline"] = qkv_gemm_roofline(B)
         out["cpu_baseline"] = cpu_baseline(args.cpu_images) if (world == 1 and not args.no_cpu_baseline) else None
         del eng, images
