@@ -27,6 +27,16 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert re.search(rf"\bT {name}\b", nm), f"{name} not exported"
     abi = int(re.search(r"#define\s+SEEDMI_ABI_VERSION\s+(\d+)", header).group(1))
     assert l.seedmi_version() == abi == lib.ABI_VERSION          # header, library and binding agree (lib.load() refuses otherwise)
+    assert l.seedmi_compute_dtype() == 0
+    # the fp16 build of the same sources (the reference's shipped compute type): same header, same export table, says what it computes in
+    build.build(verbose=False, f16=True)
+    l16 = lib.load(torch.float16)
+    assert l16 is not l and l16.seedmi_version() == abi and l16.seedmi_compute_dtype() == 1
+    nm16 = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH_F16], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", nm16), f"{name} not exported by the fp16 build"
+    with pytest.raises(lib.SeedmiError):
+        lib.load(torch.float32)                                  # no build computes in fp32: refused, not mapped to one of the two
 
 
 def _header_structs():
