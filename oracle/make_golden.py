@@ -20,7 +20,8 @@ sys.path.insert(0, ROOT)
 from oracle import ref_shims  # noqa: E402
 from seed_amd import config as C  # noqa: E402
 from seed_amd.weights import (make_tokenizer_state_dict, make_llama_state_dict, calibrate_codebook,  # noqa: E402
-                              make_detokenizer_state_dict)
+                              make_detokenizer_state_dict, make_tokenizer_peaked_state_dict, peaked_codebook, PEAKED_CASE,
+                              peaked_case_images)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -238,10 +239,48 @@ def detok_golden_fp16(name, cfg, batch, seed_w, seed_ids, ref):
     print("detok fp16", name, "rel vs fp32", ((out16.float() - out32).norm() / out32.norm()).item())
 
 
+def tokenizer_golden_peaked(ref):
+    """The peaked full-size case (VERDICT r5 item 1b; seed_amd/weights.py::make_tokenizer_peaked_state_dict) through the reference's OWN
+    modules: calibration z in fp32 -> codebook rows 0..511 = those z; the evaluated images (calibration + 0.02 pixel noise) in fp32, native
+    bf16 and native fp16.  Stored: z_cal (the codebook is a pure function of it), the three runs' ids and z, and per row the fp32 run's
+    distance from its own code to the nearest OTHER code (what the margin gate of tests/test_gpu_tokenizer.py needs)."""
+    cfg = C.SEED2
+    P = PEAKED_CASE
+    sd = make_tokenizer_peaked_state_dict(cfg, seed=P["seed_w"], value_gain=P["value_gain"], qk_gain=P["qk_gain"])
+    cal, image = peaked_case_images(cfg)
+    mods = ref_shims.build_reference_tokenizer_modules(ref, cfg)
+    load_tokenizer_weights(mods, sd)
+    qt = sd["query_tokens"].clone()
+    _, taps_cal = ref_shims.reference_get_codebook_indices(mods, qt, cal)
+    cb = peaked_codebook(taps_cal["z"], cfg.n_embed, seed=7)
+    mods.quantize.embedding.weight.data.copy_(cb)
+    ids32, taps32 = ref_shims.reference_get_codebook_indices(mods, qt, image)
+    out = dict(z_cal=taps_cal["z"].numpy(), image_sum=np.float64(image.double().sum().item()), ids_fp32=ids32.numpy().astype(np.int16),
+               z_fp32=taps32["z"].numpy(), **{k: np.float64(v) if isinstance(v, float) else np.int64(v) for k, v in P.items()})
+    for tag, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        mods = ref_shims.build_reference_tokenizer_modules(ref, cfg)
+        load_tokenizer_weights(mods, sd)
+        mods.quantize.embedding.weight.data.copy_(cb)
+        for m in (mods.visual_encoder, mods.Qformer, mods.quantize, mods.encode_task_layer):
+            m.to(dt)
+        for prm in mods.ln_vision.parameters():
+            prm.data = prm.data.to(dt).float()
+        ids16, taps16 = ref_shims.reference_get_codebook_indices(mods, qt.to(dt), image.to(dt))
+        out[f"ids_{tag}"] = ids16.numpy().astype(np.int16)
+        out[f"z_{tag}"] = taps16["z"].float().numpy()
+        print("peaked", tag, "reference vs its fp32 run: ids equal", (ids16 == ids32).float().mean().item(), "z rel",
+              ((taps16["z"].float() - taps32["z"]).norm() / taps32["z"].norm()).item())
+    want = torch.arange(P["batch"] * cfg.n_query).reshape(P["batch"], cfg.n_query)
+    print("peaked fp32 ids == own calibration row:", (ids32 == want).float().mean().item())
+    np.savez_compressed(os.path.join(GOLDEN, "tokenizer_peaked.npz"), **out)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     ref = ref_shims.load_reference_modules()
+    if sys.argv[1:] == ["peaked"]:
+        return tokenizer_golden_peaked(ref)
     vq_golden(ref)
     tokenizer_golden("tiny", C.TINY, 3, 0, 1234, ref)
     tokenizer_golden("mid", C.MID, 2, 1, 4321, ref)
@@ -254,6 +293,7 @@ def main():
     tokenizer_golden_fp16("tiny", C.TINY, 3, 0, 1234, ref)
     tokenizer_golden_fp16("mid", C.MID, 2, 1, 4321, ref)
     tokenizer_golden_fp16("full", C.SEED2, 16, 0, 1234, ref, ln_jitter=0.0, full=True)
+    tokenizer_golden_peaked(ref)
 
 
 if __name__ == "__main__":

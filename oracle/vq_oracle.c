@@ -37,7 +37,7 @@ void vq_argmin_bf16_oracle(const float* z, const float* e, int rows, int n_embed
             const float s = bf16_round(zz + ee);
             const float d = bf16_round(s - 2.0f * bf16_round(dot));
             if (bi < 0) { best = d; second = d; bi = n; if (n_embed > 1) second = 3.0e38f; }
-            else if (d < best) { second = best; best = d; bi = n; }
+            else if (d < best || (d != d && best == best)) { second = best; best = d; bi = n; }   /* torch.argmin: the first NaN is the minimum */
             else if (d < second) { second = d; }
         }
         ids[r] = bi;

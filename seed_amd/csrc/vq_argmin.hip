@@ -34,6 +34,13 @@ __global__ __launch_bounds__(256) void vq_code_sqnorm_kernel(const bf16_t* __res
     ee[i] = rbf(acc);                            // torch.sum(...) output in the model dtype
 }
 
+// torch.argmin's order on (distance, index): NaN before every number, then the smaller distance, then the smaller index
+SEEDMI_DEVINL bool vq_before(float d2, int i2, float d, int i) {
+    const bool n2 = d2 != d2, n1 = d != d;
+    if (n2 || n1) return n2 && (!n1 || i2 < i);
+    return d2 < d || (d2 == d && i2 < i);
+}
+
 // the sweep: zs holds the workgroup's VQ_ROWS rows of z (fp32 copies of half values), filled by the caller
 SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __restrict__ cb, const float* __restrict__ ee,
                             long long* __restrict__ out, int rows, int n_embed) {
@@ -53,8 +60,12 @@ SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __re
 
     float best_d[VQ_ROWS];
     int best_i[VQ_ROWS];
+    // torch.argmin (qformer_quantizer.py:98) on non-finite rows: a NaN distance is the minimum (the FIRST NaN wins), and a row whose
+    // distances are all +inf (fp16 overflow of |z|^2) returns index 0.  So the running minimum starts at (+inf, the lane's first code)
+    // - not at an index no code has - and a NaN replaces any non-NaN minimum and is never replaced.
+    const int n_first = wave * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < VQ_ROWS; ++r) { best_d[r] = INFINITY; best_i[r] = 0x7fffffff; }
+    for (int r = 0; r < VQ_ROWS; ++r) { best_d[r] = INFINITY; best_i[r] = n_first < n_embed ? n_first : 0x7fffffff; }
 
     for (int n = wave * 64 + lane; n < n_embed; n += 256) {
         float e[VQ_D];
@@ -75,7 +86,7 @@ SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __re
             for (int k = 0; k < VQ_D; ++k) dot = __builtin_fmaf(zs[r][k], e[k], dot);
             const float s = rbf(zz_s[r] + een);                  // [rows,1] + [n_embed] broadcast add -> half
             const float d = rbf(s - 2.0f * rbf(dot));            // einsum output -> half, *2 exact, subtract -> half
-            if (d < best_d[r]) { best_d[r] = d; best_i[r] = n; } // strict <: first index wins inside a lane
+            if (d < best_d[r] || (d != d && best_d[r] == best_d[r])) { best_d[r] = d; best_i[r] = n; }   // strict <: first index wins inside a lane
             __builtin_amdgcn_sched_barrier(0);                   // one row at a time: keeps z broadcasts out of the live set
         }
     }
@@ -88,7 +99,7 @@ SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __re
         for (int o = 32; o > 0; o >>= 1) {
             const float d2 = __shfl_xor(d, o, 64);
             const int i2 = __shfl_xor(i, o, 64);
-            if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+            if (vq_before(d2, i2, d, i)) { d = d2; i = i2; }
         }
         if (lane == 0) { red_d[wave][r] = d; red_i[wave][r] = i; }
     }
@@ -100,7 +111,7 @@ SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __re
         for (int w = 1; w < 4; ++w) {
             const float d2 = red_d[w][tid];
             const int i2 = red_i[w][tid];
-            if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+            if (vq_before(d2, i2, d, i)) { d = d2; i = i2; }
         }
         out[row0 + tid] = (long long)i;
     }

@@ -588,6 +588,36 @@ def test_vq_argmin_bit_exact(lib, golden_dir):
     assert torch.equal(ids_small, ref_ids), f"{(ids_small != ref_ids).sum().item()} ids differ from VectorQuantizer2's"
 
 
+@pytest.mark.parametrize("mode,dtype", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
+def test_vq_argmin_nonfinite_rows_follow_torch_argmin(mode, dtype):
+    """a row whose distances are all +inf (fp16: |z|^2 beyond 65504) or contain NaN.  torch.argmin
+    (qformer_quantizer.py:98) returns index 0 / the FIRST NaN; the kernel used to leave its start value 0x7fffffff in ids_i64 (an
+    out-of-range embedding row once 32000 is added).  Both builds, plain sweep and the head-fused sweep, against the oracle - which
+    tests/test_oracle_golden.py::test_vq_nonfinite_rows_follow_torch_argmin pins on torch and on the reference module."""
+    from oracle import seed_oracle as O
+    from _cases import nonfinite_vq_case
+    lib = L.load(dtype)
+    z, cb, cb_nan = nonfinite_vq_case(dtype)
+    for e in (cb, cb_nan):
+        zd, cbd = z.to(dtype).cuda(), e.to(dtype).cuda()
+        ee = torch.empty(e.shape[0], dtype=torch.float32, device="cuda")
+        ids = torch.full((z.shape[0],), -1, dtype=torch.int64, device="cuda")
+        L.check(lib.seedmi_vq_code_sqnorm(L.ptr(cbd), L.ptr(ee), e.shape[0], 32, L.stream_ptr()), "sqnorm")
+        L.check(lib.seedmi_vq_argmin_bf16(L.ptr(zd), 32, L.ptr(cbd), L.ptr(ee), L.ptr(ids), z.shape[0], e.shape[0], 32, L.stream_ptr()), "vq")
+        torch.cuda.synchronize()
+        want = O.vq_argmin(z, e, O.Prec(mode))
+        assert int(ids.min()) >= 0 and int(ids.max()) < e.shape[0], ids.tolist()
+        assert torch.equal(ids.cpu(), want), (mode, ids.cpu().tolist(), want.tolist())
+        # a codebook shorter than one sweep step (lanes without a code must never win a tie on +inf)
+        n_small = 100
+        ids_s = torch.full((z.shape[0],), -1, dtype=torch.int64, device="cuda")
+        cbs = cbd[:n_small].contiguous()
+        L.check(lib.seedmi_vq_code_sqnorm(L.ptr(cbs), L.ptr(ee), n_small, 32, L.stream_ptr()), "sqnorm")
+        L.check(lib.seedmi_vq_argmin_bf16(L.ptr(zd), 32, L.ptr(cbs), L.ptr(ee), L.ptr(ids_s), z.shape[0], n_small, 32, L.stream_ptr()), "vq")
+        torch.cuda.synchronize()
+        assert torch.equal(ids_s.cpu(), O.vq_argmin(z, e[:n_small], O.Prec(mode)))
+
+
 def test_vq_head_argmin_fused(lib):
     """seedmi_vq_head_argmin_bf16 (SURVEY 8a a13 -> a14): Linear(768, 32) + bias of encode_task_layer (qformer_quantizer.py:219-223) fused in
     front of the VQ sweep.  z equals the fp64 Linear rounded to half on all but a handful of round-to-nearest ties of the fp32 chain, and the
