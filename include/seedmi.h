@@ -140,8 +140,13 @@ typedef struct {
      * four 64-column spans of a tile summed in span order: deterministic) instead of N / 64 span planes; stats_ld must be even.
      * Consumer: ln_planes > 0 says ln_stats points at such planes (ln_planes of them, ln_ld rows each, over ln_cols columns in all) and not
      * at finished (mean, rstd) pairs: every tile sums its rows' ln_planes pairs in plane order and forms
-     * mean = sum / ln_cols, rstd = rsqrt(max(sumsq / ln_cols - mean^2, 0) + ln_eps) itself.  ln_planes <= 6.
-     * Both need the 256x256 kernel (large M): seedmi_gemm_tile_stats_supported(M, N) says whether a call of that shape takes it. */
+     * mean = sum / ln_cols, rstd = rsqrt(max(sumsq / ln_cols - mean^2, 0) + ln_eps) itself (one expression in every kernel: csrc/common.h
+     * seedmi_ln_finish, so an image gives the same ids whichever kernel its batch size selects).
+     * Where seedmi_gemm_tile_stats_supported(M, N) is 1 (the 256x256 kernel, large M): up to 6 TILE planes, ln_ld even.
+     * Where it is 0 (the 64x64 / 128x128 small-M kernels, e.g. one image): the PRODUCER side (stats_by_tile) is not available - those
+     * kernels write the N / 64 span planes - but the CONSUMER side is: ln_planes <= 64 SPAN planes in span order (what a small-M
+     * BIAS_RESIDUAL producer wrote: plane s = columns 64 s .. 64 s + 63), any ln_ld >= M, summed in plane order and finished in the
+     * consumer's epilogue.  seedmi_tokenize uses this for one-image batches (no seedmi_layernorm_stats_finalize launch per ViT GEMM). */
     int stats_by_tile;
     int ln_planes;
     int ln_ld;
@@ -416,12 +421,17 @@ typedef struct {
 } seedmi_llama_weights_t;
 
 /* The first seedmi_gemm_skinny_workspace_bytes() bytes of a workspace (whatever batch and T it was sized for) are the split-K area of
- * seedmi_gemm_skinny_norm_ws_bf16, used by decode steps (T == 1, batch <= 32): ZERO the workspace once after allocation (hipMemset) -
- * every step clears its hand-off flags itself, the sticky error word (32-bit word 1023) is only ever cleared by seedmi_llama_decode_status;
- * prefills never touch the area, so one workspace may serve prefills and decode steps alike. */
+ * seedmi_gemm_skinny_norm_ws_bf16, used by decode steps (T == 1, batch <= 32).  What must be initialised is ONLY that area's 1022 flag
+ * words, the tag and the sticky error word - seedmi_llama_workspace_init does it (or a hipMemset of the whole workspace followed by it);
+ * every other byte may hold anything, NaN / Inf bit patterns included: each region (activation images, their padded fragment rows beyond
+ * the batch, partial-tile images, logits staging) is written by the step before it is read, and padded rows are never reduced into real
+ * ones (tests/test_gpu_llama.py::test_llama_workspace_needs_only_its_flag_area_initialised poisons the workspace with 0xFF first).
+ * Every step clears its hand-off flags itself, the sticky error word (32-bit word 1023) is only ever cleared by
+ * seedmi_llama_decode_status; prefills never touch the area, so one workspace may serve prefills and decode steps alike. */
 size_t seedmi_llama_workspace_bytes(const seedmi_llama_weights_t* w, int batch, int T);
-/* Once after allocating a llama workspace of any (batch, T) (stream-ordered): seedmi_gemm_skinny_workspace_init on its split-K area.  A
- * workspace that skips this still computes correctly from all-zero memory, but seedmi_llama_decode_status refuses it (SEEDMI_E_SHAPE). */
+/* Once after allocating a llama workspace of any (batch, T) (stream-ordered): seedmi_gemm_skinny_workspace_init on its split-K area - the
+ * only initialisation a workspace needs (see above).  A workspace that skips it computes correctly only from all-zero memory, and
+ * seedmi_llama_decode_status refuses it (SEEDMI_E_SHAPE). */
 int seedmi_llama_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 /* LlamaForCausalLM.forward, eval, use_cache (llama_xformer.py:661-743): ids/pos int64 [B,T]; appends to the static
  * KV cache at past_len; logits bf16 [B*T_out, ldl] where T_out = T (all positions, reference behaviour) or 1

@@ -94,7 +94,15 @@ class Blip2QformerQuantizer:
         return self
 
     def float(self):
-        # (there is no fp32 compute path: fp32 callers get the default bf16 engine and fp32 outputs)
+        """fp32 callers get the bf16 engine and fp32 OUTPUTS - and are told so: the reference with ``fp16=False`` keeps fp32 parameters,
+        runs only the ViT under autocast (blip2.py:40-48, qformer_quantizer.py:290-291) and the Q-Former, task MLP and VQ distances in
+        fp32 (qformer_quantizer.py:293-303, seed_llama_tokenizer.py:35-37,58-59); this library has no fp32 compute path (BASELINE.json's
+        dtype is bf16, the shipped yaml is fp16: both are served).  Ids can differ from such a reference run on near-tie rows
+        (bf16 vs fp32: ~7 % of ids on the i.i.d. synthetic codebook, 0 % on the peaked case - profiles/r06_tokenizer_margin_coverage.json)."""
+        warnings.warn("Blip2QformerQuantizer.float(): no fp32 compute path - the Q-Former, task MLP and VQ, which the reference runs in fp32 "
+                      "when fp16=False (only its ViT is under autocast), run in bf16 here; outputs are returned as float32. "
+                      "Use .half() (the reference's shipped fp16 setting) or .bfloat16() to choose the 16-bit type explicitly.",
+                      RuntimeWarning, stacklevel=2)
         self._set_compute(torch.bfloat16)
         self._out_dtype = torch.float32
         return self

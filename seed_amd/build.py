@@ -1,7 +1,8 @@
 """Build libseedmi.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m seed_amd.build            # incremental
+    python -m seed_amd.build            # incremental; libseedmi.so (bf16) AND libseedmi_f16.so (fp16)
     python -m seed_amd.build --force
+    python -m seed_amd.build --bf16 | --f16 | --devtools      # one of them
 
 The .so stays inside the package directory (git-ignored, but it travels with gpurun snapshots) so the
 driver sees the native code that the tests load.  hipcc cross-compiles for gfx950 without a GPU.
@@ -16,6 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libseedmi.so")
 LIB_DEV = os.path.join(HERE, "libseedmi_dev.so")
+DEVTOOLS_CSRC = os.path.join(os.path.dirname(HERE), "tools", "devtools_csrc")
 LIB_F16 = os.path.join(HERE, "libseedmi_f16.so")          # the same sources with -DSEEDMI_F16: IEEE fp16 as the 16-bit element (csrc/common.h)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["capi.hip", "gemm_bf16.hip", "attn_fullrow.hip", "attn_vit.hip", "norm_misc.hip", "vq_argmin.hip", "tokenizer.hip", "detokenizer.hip", "preprocess.hip", "sample.hip", "llama.hip"]
@@ -34,7 +36,7 @@ def _deps_mtime():
 def _compile(src, force, objdir=OBJ, extra=()):
     obj = os.path.join(objdir, src.replace(".hip", ".o"))
     srcp = os.path.join(CSRC, src)
-    hdr_m = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
+    hdr_m = max(os.path.getmtime(os.path.join(d, f)) for d in (CSRC, DEVTOOLS_CSRC) if os.path.isdir(d) for f in os.listdir(d) if f.endswith((".h", ".inc")))
     hdr_m = max(hdr_m, os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "seedmi.h")))
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_m):
         return obj, False
@@ -70,7 +72,8 @@ def build(force: bool = False, verbose: bool = True, devtools: bool = False, f16
     assert not (devtools and f16)
     objdir = OBJ + ("_dev" if devtools else "_f16" if f16 else "")
     lib = LIB_DEV if devtools else LIB_F16 if f16 else LIB
-    extra = ("-DSEEDMI_DEVTOOLS",) if devtools else ("-DSEEDMI_F16",) if f16 else ()
+    # the lab build's rejected kernel variants and ablation switches live outside the product sources (tools/devtools_csrc/*.inc)
+    extra = ("-DSEEDMI_DEVTOOLS", "-I" + DEVTOOLS_CSRC) if devtools else ("-DSEEDMI_F16",) if f16 else ()
     os.makedirs(objdir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         results = list(ex.map(lambda s: _compile(s, force, objdir, extra), SOURCES))
@@ -93,4 +96,8 @@ if __name__ == "__main__":
         i = sys.argv.index("--variant")
         build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")])
     else:
-        build(force="--force" in sys.argv, devtools="--devtools" in sys.argv, f16="--f16" in sys.argv)
+        if "--devtools" in sys.argv or "--f16" in sys.argv or "--bf16" in sys.argv:
+            build(force="--force" in sys.argv, devtools="--devtools" in sys.argv, f16="--f16" in sys.argv)
+        else:                            # no selector: BOTH product libraries (the engines load libseedmi_f16.so for .half() / torch.float16)
+            build(force="--force" in sys.argv)
+            build(force="--force" in sys.argv, f16=True)

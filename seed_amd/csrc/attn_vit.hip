@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
         // the V image's pad chunk (columns 88..95) of every row: {1, 0, ..}.  It sits at chunk position 11 ^ swizzle(row); the V staging
         // below never writes it, so it is set once.
         for (int r = tid; r < VNKP; r += 64 * V16_WAVES)
-            *(uint4*)((char*)Vsm + r * (VLD * 2) + 16 * ((VCHL - 1) ^ vswz(r))) = make_uint4(0x3f80u, 0, 0, 0);
+            *(uint4*)((char*)Vsm + r * (VLD * 2) + 16 * ((VCHL - 1) ^ vswz(r))) = make_uint4((unsigned)f2bf(1.0f), 0, 0, 0);      // 1.0 in the build's 16-bit element
         __syncthreads();
     }
 
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
     __syncthreads();
     if (FLASH) {
         for (int r = tid; r < VNKP; r += 64 * V16_WAVES)
-            *(uint4*)((char*)Vsm + r * (VLD * 2) + 16 * ((VCHL - 1) ^ vswz(r))) = make_uint4(0x3f80u, 0, 0, 0);
+            *(uint4*)((char*)Vsm + r * (VLD * 2) + 16 * ((VCHL - 1) ^ vswz(r))) = make_uint4((unsigned)f2bf(1.0f), 0, 0, 0);      // 1.0 in the build's 16-bit element
         __syncthreads();
     }
     if ((int)blockIdx.x >= p.items) return;

@@ -1939,7 +1939,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
 
 #ifdef SEEDMI_DEVTOOLS
-#include "gemm_devtools.inc"
+#include "gemm_devtools.inc"          // tools/devtools_csrc/ (lab build only: -DSEEDMI_DEVTOOLS adds that directory to the include path)
 #endif
 
 // per-device launch state (function attributes are per device; so is the CU count): seedmi_internal.h
@@ -2032,7 +2032,7 @@ int launch_gemm256(const GemmParams& p, hipStream_t stream, void* sk_ws, size_t 
 }
 
 #ifdef SEEDMI_DEVTOOLS
-#include "gemm_devtools_k.inc"
+#include "gemm_devtools_k.inc"        // tools/devtools_csrc/
 #endif
 
 template <int EPI, bool LNF = false>
@@ -2239,8 +2239,9 @@ extern "C" int seedmi_gemm_bf16_ext(int M, int N, int K, const void* A, int lda,
         const bool cons_ok = ext->ln_planes <= 0 || (lnf && ext->ln_planes <= (big ? FOLD_MAX_PLANES : 64) && ext->ln_ld >= M && ext->ln_cols > 0 &&
                                                      (!big || (ext->ln_ld % 2) == 0));
         if (!prod_ok || !cons_ok || (!big && ext->stats_by_tile)) {
-            seedmi_set_error("seedmi_gemm_bf16_ext: statistics by tile need the 256x256 kernel for this shape (seedmi_gemm_tile_stats_supported), "
-                             "an even stats_ld / ln_ld >= M, stats_out resp. ln_stats + ln_colsum + bias_f32, and ln_planes <= %d", FOLD_MAX_PLANES);
+            seedmi_set_error("seedmi_gemm_bf16_ext: stats_by_tile (producer) needs the 256x256 kernel for this shape (seedmi_gemm_tile_stats_supported) and an even "
+                             "stats_ld; ln_planes (consumer) needs ln_stats + ln_colsum + bias_f32, ln_ld >= M, ln_cols > 0 and <= %d tile planes with an even "
+                             "ln_ld on the 256x256 kernel, <= 64 span planes on the small-M kernels", FOLD_MAX_PLANES);
             return SEEDMI_E_SHAPE;
         }
     }

@@ -33,11 +33,16 @@ def gather_token_ids(ids: torch.Tensor, dist=None, group=None, always_collective
         return ids
     world = dist.get_world_size(group)
     narrow = wire_int16 and ids.dtype in (torch.int64, torch.int32)
-    if narrow and ids.numel() and not ids.is_cuda:
-        # (host tensors only: a device-side range check would be a host sync on the path; the device path's ids come from the VQ kernel,
-        # whose range is its codebook size)
-        if int(ids.min()) < -32768 or int(ids.max()) > 32767:
-            raise ValueError("gather_token_ids: ids outside the int16 wire range; pass wire_int16=False")
+    if narrow and ids.numel():
+        if not ids.is_cuda:
+            if int(ids.min()) < -32768 or int(ids.max()) > 32767:
+                raise ValueError("gather_token_ids: ids outside the int16 wire range; pass wire_int16=False")
+        else:
+            # device tensors: no host sync on the path - an asynchronous device-side assertion (a kernel that traps the stream if it fails),
+            # so an id >= 32768 (e.g. LLM-vocabulary ids 32000 + code) can never wrap silently
+            wide = ids.to(torch.int32)
+            torch._assert_async(((wide >= -32768) & (wide <= 32767)).all(),
+                                "gather_token_ids: ids outside the int16 wire range; pass wire_int16=False")
     if not narrow:
         send = ids.contiguous()
         out = torch.empty((world * ids.shape[0],) + tuple(ids.shape[1:]), dtype=send.dtype, device=ids.device)

@@ -49,6 +49,7 @@ class DevicePreprocessor:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.out_dtype = out_dtype
+        self.lib_half = torch.float16 if out_dtype == torch.float16 else torch.bfloat16      # the loaded build's 16-bit element: always accepted for `out`
         self._mean = (C.c_float * 3)(*mean)
         self._std = (C.c_float * 3)(*std)
         self._ws = None
@@ -74,8 +75,8 @@ class DevicePreprocessor:
         if out is None:
             out = torch.empty(3, S, S, dtype=self.out_dtype, device=self.device)
         elif tuple(out.shape) != (3, S, S) or out.device != self.device or not out.is_contiguous() or \
-                out.dtype not in (torch.float32, self.out_dtype):
-            raise ValueError(f"out must be a contiguous [3,S,S] float32 or {self.out_dtype} tensor on this device")
+                out.dtype not in (torch.float32, self.lib_half):
+            raise ValueError(f"out must be a contiguous [3,S,S] float32 or {self.lib_half} tensor on this device")
         u8 = torch.empty(S, S, 3, dtype=torch.uint8, device=self.device) if tap_u8 else None
         need = self.lib.seedmi_preprocess_workspace_bytes(h, w, rh, rw, self.filter)
         if self._ws is None or self._ws.numel() < need:

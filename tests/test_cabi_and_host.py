@@ -218,6 +218,13 @@ try:
     raise SystemExit("an id beyond the int16 range was not refused")
 except ValueError:
     pass
+# bench.py's timed region (driver contract: barrier + sync on both sides, MAX over ranks, per-rank rows) with a stand-in encoder
+import bench
+local = torch.full((3, 4, 4, 4), float(rank + 1))
+dt, rows, out = bench.timed_steps(lambda x: fake_encode(x) % 8192, local, dist, 2, steps=3, warmup=1, use_cuda=False)
+assert out.shape == (6, 32) and out.dtype == torch.int64 and torch.equal(out[:3], fake_encode(torch.full((3, 4, 4, 4), 1.0)) % 8192)
+assert len(rows) == 2 and all(len(r) == 3 and r[0] > 0 and r[1] >= 0 and r[2] >= 0 for r in rows), rows
+assert dt >= max(r[0] for r in rows) * 3 / 1e3 * 0.999, (dt, rows)                 # the job's time is the slowest rank's
 dist.barrier()
 dist.destroy_process_group()
 print("ok", rank)
@@ -235,6 +242,22 @@ def test_data_parallel_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_bench_gpus_flag_relaunches_as_n_ranks():
+    """`python bench.py --gpus N` outside a launcher used to run one rank and print n_gpus: 1.  It now re-executes
+    itself under torch.distributed.run with N processes; inside a launcher (WORLD_SIZE set) or at N = 1 it runs in place, and a
+    WORLD_SIZE that contradicts --gpus is refused (checked here on the argv / exit path, which needs no GPU)."""
+    import bench
+    cmd = bench.relaunch_argv(8, ["--gpus", "8", "--steps", "5"], {})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
+    assert cmd[-5].endswith("bench.py")
+    assert bench.relaunch_argv(1, [], {}) is None
+    assert bench.relaunch_argv(8, ["--gpus", "8"], {"WORLD_SIZE": "8"}) is None
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in (r.stderr + r.stdout)
 
 
 def test_dp_pretokenizer_tool_shards_and_format(tmp_path):

@@ -693,6 +693,39 @@ def test_split_k_error_word_is_sticky_and_reported():
     assert eng.lib.seedmi_llama_decode_status(Ct.byref(eng.w), B, L.ptr(raw), raw.numel(), L.stream_ptr()) == 0
 
 
+@pytest.mark.parametrize("B", [5, 32])
+def test_llama_workspace_needs_only_its_flag_area_initialised(B):
+    """workspaces are torch.empty + seedmi_llama_workspace_init since round 5 (which writes the 1022 flag words, the tag and
+    the error word only).  Poison every byte with 0xFF (NaN bit patterns in every 16-bit and fp32 region, incl. the padded fragment rows
+    beyond the batch) before the init: prefill logits, every decode step's logits, the tokens and the status must be BIT-equal to a run
+    on a zeroed-then-initialised workspace - i.e. include/seedmi.h's contract (only the flag area must be initialised) is what the code
+    needs.  B = 5 pads 11 of 16 fragment rows; B = 32 takes the split-K hand-off with cut tiles."""
+    from dataclasses import replace
+    from seed_amd import lib as L
+    cfg = replace(C.LLAMA_8B, layers=2)
+    sd = make_llama_state_dict(cfg, seed=1, dtype=torch.bfloat16)
+    prompt = torch.randint(3, 32000, (B, 9), generator=torch.Generator().manual_seed(2)).cuda()
+    runs = []
+    for poison in (None, 0xFF):
+        eng = LlamaEngine(sd, cfg, device="cuda", batch_cap=B, tmax=64)
+        made = []
+
+        def new_workspace(nbytes, eng=eng, poison=poison, made=made):
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda") if poison is None else torch.full((nbytes,), poison, dtype=torch.uint8, device="cuda")
+            L.check(eng.lib.seedmi_llama_workspace_init(L.ptr(ws), ws.numel(), L.stream_ptr()), "init")
+            made.append(ws)
+            return ws
+        eng.new_workspace = new_workspace
+        toks, steps = eng.greedy_decode(prompt, 6)                 # eager prefill + 5 decode steps, ends with decode_status()
+        toks_g = eng.greedy_decode_graph(prompt, 6)                # and the captured step replayed from a hipGraph on the same workspace
+        torch.cuda.synchronize()
+        assert made, "the engine did not allocate through new_workspace"
+        assert torch.isfinite(steps.float()).all()
+        runs.append((toks.cpu(), steps.cpu(), toks_g.cpu()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2])
+    assert torch.equal(runs[0][1].view(torch.int16), runs[1][1].view(torch.int16)), "logits depend on uninitialised workspace bytes"
+
+
 def test_padded_attention_mask_warns(tmp_path):
     """VERDICT r3 weak 12 / SURVEY H7: padding masks are not applied (the reference's xformers path ignores them too); a mask that
     contains zeros now says so instead of silently answering for padding.  A mask of ones stays silent."""
