@@ -70,6 +70,8 @@ int seedmi_check_device(void);
  *                                                        producer waves) | 128x128 | persistent 256x256
  * = gemm_small             1 | 0                         the automatic selection may take the 64x64 kernel where 128x128 tiles cannot give every
  *                                                        CU a workgroup (one image: M = 257)
+ * = gemm64_xcd             1 | 0                         64x64 kernel: XCD-contiguous tile order (the m-tiles sharing a W panel on one XCD) |
+ *                                                        workgroup b takes tile b
  * = gemm_sched             -1 = 8273 | 24657 | 57425 | 0 schedule of the 256x256 kernel: two-phase K-tile, position-free body | + seam (the next
  *                                                        tile's operands requested by the K loop's last K-tiles) | + peeled first K-tiles whose
  *                                                        waits leave the output stores in flight | the plain four-phase schedule of round 2

@@ -74,6 +74,7 @@ struct GemmParams {
     bf16_t* C; int ldc;
     int tiles_m, tiles_n;
     int group_m;                // m-tiles walked per group of the tile order (L2 locality)
+    int xcd_map;                // 64x64 kernel: 1 = XCD-contiguous tile order ("gemm64_xcd", default), 0 = workgroup b takes tile b
 #ifdef SEEDMI_DEVTOOLS
     unsigned long long* dbg;    // phase clock stamps of workgroup 0 (tools/gemm_phase_times.py), or null
     int skip_epilogue;          // timing ablations, seedmi_set_option("gemm_ablate", 32|33|34): 1 = no epilogue, 2 = epilogue without
@@ -279,11 +280,27 @@ SEEDMI_DEVINL void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m
                 // partial planes (the producer GEMM's span-major (sum, sum of squares) pairs) instead of finished statistics: the row's pairs
                 // summed in plane order and finished exactly as seedmi_layernorm_stats_finalize does - the small-M kernels (64x64, 128x128)
                 // then need no finalize launch between two GEMMs (one image: 77 launches of ~6.7 us)
+                // (16 planes requested at a time, THEN summed in plane order: written as one load + one add per plane hipcc made it a loop of
+                //  `global_load; s_waitcnt vmcnt(0); add` - 22 serial L2 round trips per epilogue, most of a one-image QKV / fc1 launch)
                 float s1 = 0.f, s2 = 0.f;
-                for (int pl = 0; pl < p.ln_planes; ++pl) {
-                    const float2 t = *(const float2*)((const char*)p.ln_stats + 8 * ((size_t)pl * (size_t)p.ln_ld + row));
-                    s1 += t.x; s2 += t.y;
-                }
+                // (requested 16 / 4 / 1 planes at a time and THEN summed in plane order - 22 planes = 16 + 4 + 1 + 1: four L2 round trips; written
+                //  as one load + one add per plane hipcc emits `global_load; s_waitcnt vmcnt(0); add` per plane, 22 serial round trips per
+                //  epilogue.  No masked lanes: a clamped-and-masked 16-wide form measured NOT bit-equal to the finalize kernel's chain.)
+                const char* pb = (const char*)p.ln_stats + 8 * (size_t)row;
+                const size_t pstride = 8 * (size_t)p.ln_ld;
+                int pl = 0;
+                auto take = [&](auto nconst) {
+                    constexpr int NP = decltype(nconst)::value;
+                    float2 t[NP];
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) t[j] = *(const float2*)(pb + (size_t)(pl + j) * pstride);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) { s1 += t[j].x; s2 += t[j].y; }
+                    pl += NP;
+                };
+                while (pl + 16 <= p.ln_planes) take(std::integral_constant<int, 16>());
+                while (pl + 4 <= p.ln_planes) take(std::integral_constant<int, 4>());
+                while (pl < p.ln_planes) take(std::integral_constant<int, 1>());
                 rstat[mi] = seedmi_ln_finish(s1, s2, p.ln_inv_cols, p.ln_eps);
             } else {
                 rstat[mi] = *(const float2*)((const char*)p.ln_stats + 8u * row);
@@ -806,8 +823,19 @@ __global__ __launch_bounds__(PROD ? 512 : 256, NS <= 4 ? 2 : 1) void gemm64_kern
     const bool producer = PROD && wave >= 4;
     const int sw = PROD ? (wave & 3) : wave;          // staging role: rows [16 sw, 16 sw + 16) of both tiles
     const int li = lane & 15, g = lane >> 4;
-    // m-tiles fastest: the (few) m-tiles that share a W panel are dispatched next to each other
-    const int tm = (int)blockIdx.x % p.tiles_m, tn = (int)blockIdx.x / p.tiles_m;
+    // m-tiles fastest, XCD-contiguous: workgroup b runs on XCD b % 8 (observed placement; a speed choice only), so XCD x takes the x-th
+    // eighth of the (n-tile, m-tile) order - the (few) m-tiles that share a W panel then run next to each other ON ONE XCD and the panel
+    // crosses the fabric once instead of once per m-tile (at M = 257 a plain b -> tile map put the five m-tiles of a panel on five XCDs:
+    // 5 x |W| through the fabric per GEMM of a one-image pass, whose floor is 1 x |W|)
+    int tm, tn;
+    {
+        const int nt = p.tiles_m * p.tiles_n, bid = (int)blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+        const int cs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int t = p.xcd_map ? cs + idx : bid;
+        tm = t % p.tiles_m;
+        tn = t / p.tiles_m;
+    }
     const int m0 = tm * 64, n0 = tn * 64;
     uint32_t offA[2], offW[2];
 #pragma unroll
@@ -2051,6 +2079,7 @@ int launch_gemm128(const GemmParams& p, hipStream_t stream) {
 
 
 std::atomic<int> g_gemm_small{1};    // "gemm_small": the automatic selection may take the 64x64 kernel (1) or stays with 128x128 / 256x256 (0: A/B)
+std::atomic<int> g_gemm64_xcd{1};    // "gemm64_xcd": XCD-contiguous tile order of the 64x64 kernel (1, default) or workgroup b = tile b (0: A/B); same bits
 std::atomic<int> g_gemm64_prod{1};   // "gemm" = 65 selects the four-wave form of the 64x64 kernel (no producer waves) for A/B; 64 / automatic: producer waves
 
 template <int EPI, bool LNF, int NS, bool PROD>
@@ -2070,6 +2099,7 @@ template <int EPI, bool LNF = false>
 int launch_gemm64(GemmParams p, hipStream_t stream) {
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_n = (p.N + 63) / 64;
+    p.xcd_map = g_gemm64_xcd;
     // one workgroup per CU with a deep ring when the tiles do not fill the CUs once; two per CU with half the ring otherwise
     const bool deep = (long long)p.tiles_m * p.tiles_n <= device_cus(current_device());
     if (g_gemm64_prod) return deep ? launch_gemm64_ns<EPI, LNF, 8, true>(p, stream) : launch_gemm64_ns<EPI, LNF, 4, true>(p, stream);
@@ -2149,6 +2179,11 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         g_gemm_small = value;
         return SEEDMI_OK;
     }
+    if (key && !strcmp(key, "gemm64_xcd") && (value == 0 || value == 1)) {
+        g_gemm64_xcd = value;
+        return SEEDMI_OK;
+    }
+
     if (key && !strcmp(key, "gemm_group_m") && value >= 0 && value <= 64) {
         g_group_m = value;
         return SEEDMI_OK;

@@ -30,7 +30,9 @@ def _rel(a, b):
 _OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 # floors under the measured share of rows the margin gate covers (profiles/r06_tokenizer_margin_coverage.json): the "no id flips on a
 # confident row" assertion must not go vacuous
-COVERAGE_FLOOR = {"tiny": 0.0, "mid": 0.0, "seed2-full": 0.0, "tiny-fp16": 0.0, "mid-fp16": 0.0, "seed2-full-fp16": 0.0}
+# measured (round 6): tiny 0.583, mid 0.375, seed2-full 0.094 (i.i.d. codebook: top-2 gaps ~ the bf16 resolution of the distance itself), fp16: 0.875 / 0.891 / 0.703;
+# the peaked case below covers 1.000 of its rows in both builds
+COVERAGE_FLOOR = {"tiny": 0.45, "mid": 0.25, "seed2-full": 0.05, "tiny-fp16": 0.75, "mid-fp16": 0.75, "seed2-full-fp16": 0.55}
 
 
 def _record(name, entry):

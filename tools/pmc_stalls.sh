@@ -18,7 +18,9 @@ for P in \
   "SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
   "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr" \
   "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum" \
-  "TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_TAG_STALL_sum"; do
+  "TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_TAG_STALL_sum" \
+  "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TCP_LATENCY_sum" \
+  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_LEVEL_sum TCC_BUBBLE_sum"; do
   i=$((i+1))
   timeout 180 rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pmcs_p$i -- $CMD > /tmp/pmcs_p$i.log 2>&1 || { echo "pass $i ($P) failed:"; tail -3 /tmp/pmcs_p$i.log; }
 done
@@ -48,6 +50,10 @@ if durs and out.get("GRBM_GUI_ACTIVE"):
     clk = out["GRBM_GUI_ACTIVE"] / 8 / ns
     d.update(launch_ns_in_pmc_pass=ns, effective_clock_ghz=clk, mfma_busy_frac=out.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (out["GRBM_GUI_ACTIVE"] / 8 * 1024),
              mfma_valu_coexec_frac=out.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0) / (out["GRBM_GUI_ACTIVE"] / 8 * 1024))
+if out.get("TCP_TCC_READ_REQ_sum"):
+    d["avg_l2_read_round_trip_cycles"] = out.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / out["TCP_TCC_READ_REQ_sum"]
+if out.get("TCC_HIT_sum") is not None and out.get("TCC_MISS_sum") is not None and (out["TCC_HIT_sum"] + out["TCC_MISS_sum"]) > 0:
+    d["l2_hit_rate"] = out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"])
 if out.get("TCC_EA0_RDREQ_sum"):
     d["ea_read_requests_to_dram_share"] = out.get("TCC_EA0_RDREQ_DRAM_sum", 0) / out["TCC_EA0_RDREQ_sum"]
     d["ea_read_bytes"] = (out["TCC_EA0_RDREQ_sum"] - out.get("TCC_EA0_RDREQ_32B_sum", 0)) * 64 + out.get("TCC_EA0_RDREQ_32B_sum", 0) * 32

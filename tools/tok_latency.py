@@ -47,7 +47,7 @@ for B in BATCHES:
         res[f"B={B} {spec or 'defaults'}"] = {"median_us": round(ts[len(ts) // 2] * 1e6, 1), "min_us": round(ts[0] * 1e6, 1),
                                               "images_per_s": round(B / ts[len(ts) // 2], 1), "ids_equal_to_first_set": same}
         for kv in filter(None, spec.split(",")):
-            lib.seedmi_set_option(kv.split("=")[0].encode(), 0 if kv.split("=")[0] != "gemm_sched" else -1)
+            lib.seedmi_set_option(kv.split("=")[0].encode(), {"gemm_sched": -1, "gemm64_xcd": 1, "gemm_small": 1, "attn_small": 1, "vq_split": 1}.get(kv.split("=")[0], 0))
         print(f"B={B} {spec or 'defaults'}:", json.dumps(res[f"B={B} {spec or 'defaults'}"]), flush=True)
 os.makedirs(os.path.dirname(os.environ.get("OUT", "gpurun_out/tok_latency.json")) or ".", exist_ok=True)
 json.dump(res, open(os.environ.get("OUT", "gpurun_out/tok_latency.json"), "w"), indent=1)
