@@ -93,6 +93,8 @@ int seedmi_check_device(void);
  * = attn_vit               5 | 0 | 1 | 2 | 3             ViT attention (257 tokens, head dim 88): staggered sixteen-wave | generic full-row |
  *                                                        twelve-wave | sixteen-wave | sixteen-wave, 16-byte stores
  * = attn_xcd               1 | 0                         all heads of an image on one XCD (attn_vit 5, full launches)
+ * = attn_small             1 | 2..16 | 0                 ViT attention launches with fewer (image, head) items than half the CUs (one image: 16):
+ *                                                        every item's query tiles split over several workgroups (automatic | that many) | never
  * = attn_store_wait        1 | 0                         attn_vit 5: the wait for the next item's K / Q leaves the output stores in flight
  * = attn_trv               1 | 0                         generic kernel: V through ds_read_b64_tr_b16 | a transposed LDS image */
 int seedmi_set_option(const char* key, int value);

@@ -239,6 +239,7 @@ int seedmi_attn_set_option(const char* key, int value) {
 #endif
     if (!strcmp(key, "attn_store_wait") && (value == 0 || value == 1)) return seedmi_attn_vit_store_wait(value);
     if (!strcmp(key, "attn_xcd") && (value == 0 || value == 1)) return seedmi_attn_vit_xcd(value);
+    if (!strcmp(key, "attn_small") && value >= 0 && value <= 16) return seedmi_attn_vit_small(value);
     return SEEDMI_E_SHAPE;
 }
 

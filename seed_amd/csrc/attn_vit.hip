@@ -39,6 +39,8 @@ struct VitAttnParams {
     float scale;
     int store_wait;               // 16-wave kernel: 1 = the K / Q wait tolerates the previous item's output stores (seedmi_set_option "attn_store_wait")
     int xcd_map;                  // staggered kernel: 1 = all heads of an image on ONE XCD (see attn_vit16s_kernel; "attn_xcd")
+    int qsplit;                   // lock-step 16-wave kernel: an (image, head) item is shared by qsplit workgroups (1, 2, 4, 8 or 16), each running 16 / qsplit of
+                                  // its query tiles (part 0 also the side row): small launches (one image = 16 items for 256 CUs)
 #ifdef SEEDMI_DEVTOOLS
     unsigned long long* dbg;      // phase clock stamps of workgroup 0 (tools/attn_phase_times.py): [wave][item][6]
 #endif
@@ -384,7 +386,14 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
         }
     };
 
-    int item = blockIdx.x;
+    // Small launches: p.qsplit workgroups share an item.  A query tile is ONE wave's private work from its Q fragment to its output rows
+    // (K, V and the side row's LDS copy are only read), so which workgroup's wave runs it changes nothing in its arithmetic: bit-identical to
+    // the unsplit launch and to the staggered kernel (tests).  Part s runs the tiles of waves [s 16 / S, (s + 1) 16 / S) - one per SIMD
+    // first - and part 0 the side row; every part stages the whole K / Q / V images (L2-resident after the first part's pass).
+    const int S = p.qsplit, part = S > 1 ? (int)blockIdx.x % S : 0;
+    const bool main_on = S <= 1 || wave / (V16_WAVES / S) == part, side_on = part == 0;
+    int item = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x;
+    const int item_step = S > 1 ? (int)gridDim.x / S : (int)gridDim.x;
     if (item >= p.items) return;
     stage(p.K, p.ldk, Ksm, item);
     stage(p.Q, p.ldq, Qsm, item);
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
 
         // ---- S^T = K Q^T for query tile `wave`, softmax, P packed to bf16 MFMA operands
         bf16x8 pf[VKK];
-        {
+        if (main_on) {
             // fragment addresses (bytes): row li of a 16-row tile, chunk (4 ks + g) ^ swizzle(li); + 16 * 192 bytes per tile (immediate)
             const int lane = fresh_lane(), li = lane & 15, g = lane >> 4;
             int koff[3];
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
             __builtin_amdgcn_sched_barrier(0);
         }
         V16STAMP(3);
-        if (wave == side_a) {
+        if (side_on && wave == side_a) {
             // ---- row 256 (query tile 16, rows 257..271 of the Q image are zero): operands swapped, S[q = 4 g + r][key = 16 kt + li].
             //      Only q == 0 exists: lanes 0..15, accumulator register 0.
             const int lane = fresh_lane(), li = lane & 15, g = lane >> 4;
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         V16STAMP(5);
-        const int next = item + gridDim.x;
+        const int next = item + item_step;
         const bool more = next < p.items;
         if (more) {
             stage(p.K, p.ldk, Ksm, next);
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
                 }
             }
         };
-        {
+        if (main_on) {
             f32x4 o[VHT];
 #pragma unroll
             for (int nn = 0; nn < VHT; ++nn) o[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16_kernel(VitAttnParam
             stores_behind = p.store_wait ? (WIDE ? VHT / 2 : VHT) : 0;
         }
         V16STAMP(7);
-        if (wave == side_b) {
+        if (side_on && wave == side_b) {
             // row 256: P^T operand straight from the side row (lane group g takes keys 32 kk + 4 g .. + 3 and + 16 .. : every column of
             // the operand is the same row, only column li == 0 is stored)
             f32x4 o[VHT];
@@ -1225,6 +1234,8 @@ __global__ __launch_bounds__(64 * V16_WAVES) void attn_vit16s_kernel(VitAttnPara
 std::atomic<int> g_attn_vit{5};
 std::atomic<int> g_attn_store_wait{1};
 std::atomic<int> g_attn_xcd{1};
+std::atomic<int> g_attn_small{1};      // "attn_small": 1 = launches with fewer items than half the CUs split every item's query tiles over several workgroups
+                                       // (automatic factor), 2 / 4 / 8 / 16 = that factor, 0 = never (A/B); same bits
 #undef V16STAMP
 #undef V16DUMP
 #ifdef SEEDMI_DEVTOOLS
@@ -1238,6 +1249,7 @@ unsigned long long* g_attn_dbg = nullptr;
 extern "C" int seedmi_attn_vit_timing(void* buf) { g_attn_dbg = (unsigned long long*)buf; return SEEDMI_OK; }
 #endif
 
+int seedmi_attn_vit_small(int v) { g_attn_small = v; return SEEDMI_OK; }
 int seedmi_attn_vit_enabled() { return g_attn_vit; }
 int seedmi_attn_vit_set(int v) { g_attn_vit = v; return SEEDMI_OK; }
 int seedmi_attn_vit_store_wait(int v) { g_attn_store_wait = v; return SEEDMI_OK; }
@@ -1254,6 +1266,7 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
     p.n = nq; p.heads = heads; p.items = batch * heads; p.scale = scale;
     p.store_wait = g_attn_store_wait.load(std::memory_order_relaxed);
     p.xcd_map = 0;
+    p.qsplit = 1;
 #ifdef SEEDMI_DEVTOOLS
     p.dbg = g_attn_dbg;
 #endif
@@ -1268,6 +1281,22 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)attn_vit_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
+    }
+    // Small launches: fewer items than half the CUs (one image: 16 items; the reference scripts tokenize ONE image) -> the lock-step 16-wave
+    // kernel with every item's query tiles split over `qsplit` workgroups (17.6 us per ViT block at one image, 16 CUs busy, before).
+    const int small = g_attn_small.load(std::memory_order_relaxed);
+    if (small && g_attn_vit >= 2 && nq == V16_N && round_scores && 2 * p.items <= n_cu) {
+        int S = small > 1 ? small : (4 * p.items <= n_cu ? 4 : 2);
+        S = (S >= 16) ? 16 : (S >= 8 ? 8 : (S >= 4 ? 4 : 2));
+        while (S > 2 && p.items * S > n_cu) S >>= 1;
+        p.qsplit = S;
+        static bool attr16q_dev[SEEDMI_MAX_DEVICES] = {};
+        if (!attr16q_dev[dev]) {
+            (void)hipFuncSetAttribute((const void*)attn_vit16_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V16_LDS_BYTES);
+            attr16q_dev[dev] = true;
+        }
+        hipLaunchKernelGGL((attn_vit16_kernel<true, 1>), dim3(p.items * S), dim3(64 * V16_WAVES), V16_LDS_BYTES, (hipStream_t)stream, p);
+        return seedmi_check_launch("attn_vit16 (split query tiles)");
     }
     if (g_attn_vit >= 2 && nq == V16_N && round_scores) {        // (unrounded scores: only tests ask for them; the 12-wave kernel serves those)
         static bool attr16_dev[SEEDMI_MAX_DEVICES] = {};

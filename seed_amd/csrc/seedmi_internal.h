@@ -29,6 +29,7 @@ int seedmi_attention_vit_try(const void* Q, int ldq, const void* K, int ldk, con
                              int batch, int heads, int head_dim, int nq, int nk, float scale, int causal, int round_scores,
                              void* stream);
 int seedmi_attn_vit_set(int v);
+int seedmi_attn_vit_small(int v);        // "attn_small": q-tile split of small ViT attention launches (1 auto, 2..8 fixed factor, 0 off)
 int seedmi_attn_vit_xcd(int v);          // "attn_xcd": the staggered ViT kernel's XCD-aware item walk (1, default)
 int seedmi_attn_vit_store_wait(int v);   // "attn_store_wait": the 16-wave ViT kernel's K / Q wait leaves the previous item's output stores in flight (1, default)
 

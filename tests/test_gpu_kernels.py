@@ -588,6 +588,37 @@ def test_vq_argmin_bit_exact(lib, golden_dir):
     assert torch.equal(ids_small, ref_ids), f"{(ids_small != ref_ids).sum().item()} ids differ from VectorQuantizer2's"
 
 
+@pytest.mark.parametrize("B", [1, 2, 4, 7])
+def test_vit_attention_small_launch_split_is_bit_identical(lib, B):
+    """Round 6: a ViT attention launch with fewer (image, head) items than half the CUs - one image is 16 items for 256 CUs, and one image is
+    what the reference scripts tokenize - splits every item's query tiles over 2 / 4 / 8 / 16 workgroups of the lock-step 16-wave kernel.
+    A query tile is one wave's private work, so the split may not change a bit: every factor against the unsplit staggered kernel (the one
+    large batches take), i.e. an image alone and the same image inside a 256-batch still see the same attention output."""
+    H, hd, n = 16, 88, 257
+    C = H * hd
+    gen = torch.Generator().manual_seed(40 + B)
+    qkv = bf(rand(gen, B * n, 3 * C)).cuda()
+    scale = hd ** -0.5
+
+    def run(small):
+        L.check(lib.seedmi_set_option(b"attn_small", small), "set_option")
+        out = torch.full((B * n, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(lib.seedmi_attention_bf16(L.ptr(qkv), 3 * C, L.ptr(qkv[:, C:]), 3 * C, L.ptr(qkv[:, 2 * C:]), 3 * C, L.ptr(out), C, B, H, hd, n, n, scale,
+                                          0, 1, L.stream_ptr()), "attention")
+        torch.cuda.synchronize()
+        return out
+    try:
+        ref = run(0)                                             # the staggered 16-wave kernel, one workgroup per item
+        assert torch.isfinite(ref.float()).all()
+        for small in (1, 2, 4, 8, 16):
+            got = run(small)
+            assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), f"attn_small={small} changed {(got != ref).sum().item()} values"
+    finally:
+        lib.seedmi_set_option(b"attn_small", 1)
+    want = ref_attention(qkv[:, :C].float().view(B, n, C), qkv[:, C:2 * C].float().reshape(B, n, C), qkv[:, 2 * C:].float().reshape(B, n, C), H, scale, False)
+    assert_close_bf16(ref.view(B, n, C), want, f"vit attention B={B}", atol_ulps=2.5, frac=0.995)
+
+
 @pytest.mark.parametrize("mode,dtype", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
 def test_vq_argmin_nonfinite_rows_follow_torch_argmin(mode, dtype):
     """a row whose distances are all +inf (fp16: |z|^2 beyond 65504) or contain NaN.  torch.argmin
