@@ -21,6 +21,7 @@ namespace {
 
 constexpr int VQ_D = 32;
 constexpr int VQ_ROWS = 8;
+constexpr int VQ_SMALL_ROWS = 256;               // up to this many rows (8 images) the one-row, sixteen-wave shape of the sweep is launched
 
 __global__ __launch_bounds__(256) void vq_code_sqnorm_kernel(const bf16_t* __restrict__ cb, float* __restrict__ ee, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,12 +42,17 @@ SEEDMI_DEVINL bool vq_before(float d2, int i2, float d, int i) {
     return d2 < d || (d2 == d && i2 < i);
 }
 
-// the sweep: zs holds the workgroup's VQ_ROWS rows of z (fp32 copies of half values), filled by the caller
-SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __restrict__ cb, const float* __restrict__ ee,
+// the sweep: zs holds the workgroup's ROWS rows of z (fp32 copies of half values), filled by the caller.  Two shapes of the same sweep:
+// ROWS = 8 rows x 4 waves (batches: thousands of rows, the codebook re-streamed once per 8 rows) and ROWS = 1 row x 16 waves (ONE image is
+// 32 rows: four 8-row workgroups swept 8192 codes x 8 rows each on four CUs, 105 us; thirty-two 1024-thread workgroups take ~a tenth).
+// A lane still visits its codes in increasing order and every reduction picks by (NaN first, distance, index): the same winner.
+template <int ROWS, int NW>
+SEEDMI_DEVINL void vq_sweep(const float (&zs)[ROWS][VQ_D], const bf16_t* __restrict__ cb, const float* __restrict__ ee,
                             long long* __restrict__ out, int rows, int n_embed) {
+    constexpr int VQ_ROWS = ROWS;                                    // (shadows the batch shape's constant inside the sweep)
     __shared__ float zz_s[VQ_ROWS];
-    __shared__ float red_d[4][VQ_ROWS];
-    __shared__ int red_i[4][VQ_ROWS];
+    __shared__ float red_d[NW][VQ_ROWS];
+    __shared__ int red_i[NW][VQ_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * VQ_ROWS;
     __syncthreads();
@@ -67,7 +73,7 @@ SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __re
 #pragma unroll
     for (int r = 0; r < VQ_ROWS; ++r) { best_d[r] = INFINITY; best_i[r] = n_first < n_embed ? n_first : 0x7fffffff; }
 
-    for (int n = wave * 64 + lane; n < n_embed; n += 256) {
+    for (int n = wave * 64 + lane; n < n_embed; n += 64 * NW) {
         float e[VQ_D];
         const uint4* ep = (const uint4*)(cb + (size_t)n * VQ_D);
 #pragma unroll
@@ -108,7 +114,7 @@ SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __re
         float d = red_d[0][tid];
         int i = red_i[0][tid];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NW; ++w) {
             const float d2 = red_d[w][tid];
             const int i2 = red_i[w][tid];
             if (vq_before(d2, i2, d, i)) { d = d2; i = i2; }
@@ -117,18 +123,19 @@ SEEDMI_DEVINL void vq_sweep(const float (&zs)[VQ_ROWS][VQ_D], const bf16_t* __re
     }
 }
 
-__global__ __launch_bounds__(256) void vq_argmin_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ cb,
-                                                        const float* __restrict__ ee, long long* __restrict__ out,
-                                                        int rows, int n_embed) {
-    __shared__ __attribute__((aligned(16))) float zs[VQ_ROWS][VQ_D];
+template <int ROWS, int NW>
+__global__ __launch_bounds__(64 * NW) void vq_argmin_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ cb,
+                                                            const float* __restrict__ ee, long long* __restrict__ out,
+                                                            int rows, int n_embed) {
+    __shared__ __attribute__((aligned(16))) float zs[ROWS][VQ_D];
     const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * VQ_ROWS;
-    for (int idx = tid; idx < VQ_ROWS * VQ_D; idx += 256) {
+    const int row0 = blockIdx.x * ROWS;
+    for (int idx = tid; idx < ROWS * VQ_D; idx += 64 * NW) {
         const int r = idx / VQ_D, k = idx - r * VQ_D;
         const int row = min(row0 + r, rows - 1);
         zs[r][k] = bf2f(z[(size_t)row * ldz + k]);
     }
-    vq_sweep(zs, cb, ee, out, rows, n_embed);
+    vq_sweep<ROWS, NW>(zs, cb, ee, out, rows, n_embed);
 }
 
 // encode_task_layer's second Linear (qformer_quantizer.py:219-223: Linear(768, 32) after the Tanh) fused in front of the sweep
@@ -136,22 +143,23 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const bf16_t* __restrict
 // z[r][k] = half(sum_j t[r][j] w[k][j] + b[k]) with a sequential fp32 chain, z goes straight into the sweep's LDS copy and, when asked
 // for (taps), to memory.  No [rows, 32] round trip, no 32-column launch of a 128-column GEMM tile.
 constexpr int VQ_HMAX = 1024;                    // widest hidden size staged (Q-Former: 768)
-__global__ __launch_bounds__(256) void vq_head_argmin_kernel(const bf16_t* __restrict__ t, int ldt, int hidden, const bf16_t* __restrict__ w1,
+template <int ROWS, int NW>
+__global__ __launch_bounds__(64 * NW) void vq_head_argmin_kernel(const bf16_t* __restrict__ t, int ldt, int hidden, const bf16_t* __restrict__ w1,
                                                              int ldw, const bf16_t* __restrict__ b1, const bf16_t* __restrict__ cb,
                                                              const float* __restrict__ ee, long long* __restrict__ out,
                                                              bf16_t* __restrict__ z_out, int ldz, int rows, int n_embed) {
-    __shared__ __attribute__((aligned(16))) float zs[VQ_ROWS][VQ_D];
-    __shared__ __attribute__((aligned(16))) bf16_t ts[VQ_ROWS][VQ_HMAX];
+    __shared__ __attribute__((aligned(16))) float zs[ROWS][VQ_D];
+    __shared__ __attribute__((aligned(16))) bf16_t ts[ROWS][VQ_HMAX];
     const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * VQ_ROWS;
+    const int row0 = blockIdx.x * ROWS;
     const int chunks = hidden >> 3;
-    for (int idx = tid; idx < VQ_ROWS * chunks; idx += 256) {
+    for (int idx = tid; idx < ROWS * chunks; idx += 64 * NW) {
         const int r = idx / chunks, c = idx - r * chunks;
         const int row = min(row0 + r, rows - 1);
         *(uint4*)&ts[r][8 * c] = *(const uint4*)(t + (size_t)row * ldt + 8 * c);
     }
     __syncthreads();
-    {
+    if (tid < ROWS * VQ_D) {                                        // (z[r][k]: one sequential fp32 chain per element, whatever the workgroup's shape)
         const int r = tid >> 5, k = tid & 31;
         const bf16_t* wr = w1 + (size_t)k * ldw;
         float acc = 0.f;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256) void vq_head_argmin_kernel(const bf16_t* __res
         zs[r][k] = bf2f(zh);
         if (z_out && row0 + r < rows) z_out[(size_t)(row0 + r) * ldz + k] = zh;
     }
-    vq_sweep(zs, cb, ee, out, rows, n_embed);
+    vq_sweep<ROWS, NW>(zs, cb, ee, out, rows, n_embed);
 }
 
 }  // namespace
@@ -193,9 +201,12 @@ extern "C" int seedmi_vq_argmin_bf16(const void* z, int ldz, const void* codeboo
         seedmi_set_error("seedmi_vq_argmin_bf16: codebook must be 16-byte aligned");
         return SEEDMI_E_ALIGN;
     }
-    hipLaunchKernelGGL(vq_argmin_kernel, dim3((rows + VQ_ROWS - 1) / VQ_ROWS), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)z, ldz, (const bf16_t*)codebook, (const float*)ee_f32, (long long*)ids_i64, rows,
-                       n_embed);
+    if (rows <= VQ_SMALL_ROWS)
+        hipLaunchKernelGGL((vq_argmin_kernel<1, 16>), dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)z, ldz, (const bf16_t*)codebook,
+                           (const float*)ee_f32, (long long*)ids_i64, rows, n_embed);
+    else
+        hipLaunchKernelGGL((vq_argmin_kernel<VQ_ROWS, 4>), dim3((rows + VQ_ROWS - 1) / VQ_ROWS), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)z, ldz, (const bf16_t*)codebook, (const float*)ee_f32, (long long*)ids_i64, rows, n_embed);
     return seedmi_check_launch("vq_argmin");
 }
 
@@ -211,8 +222,12 @@ extern "C" int seedmi_vq_head_argmin_bf16(const void* t, int ldt, int hidden, co
         seedmi_set_error("seedmi_vq_head_argmin_bf16: t, w and the codebook must be 16-byte aligned");
         return SEEDMI_E_ALIGN;
     }
-    hipLaunchKernelGGL(vq_head_argmin_kernel, dim3((rows + VQ_ROWS - 1) / VQ_ROWS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, ldt,
-                       hidden, (const bf16_t*)w, ldw, (const bf16_t*)bias, (const bf16_t*)codebook, (const float*)ee_f32, (long long*)ids_i64,
-                       (bf16_t*)z_out, ldz, rows, n_embed);
+    if (rows <= VQ_SMALL_ROWS)
+        hipLaunchKernelGGL((vq_head_argmin_kernel<1, 16>), dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)t, ldt, hidden, (const bf16_t*)w,
+                           ldw, (const bf16_t*)bias, (const bf16_t*)codebook, (const float*)ee_f32, (long long*)ids_i64, (bf16_t*)z_out, ldz, rows, n_embed);
+    else
+        hipLaunchKernelGGL((vq_head_argmin_kernel<VQ_ROWS, 4>), dim3((rows + VQ_ROWS - 1) / VQ_ROWS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t,
+                           ldt, hidden, (const bf16_t*)w, ldw, (const bf16_t*)bias, (const bf16_t*)codebook, (const float*)ee_f32, (long long*)ids_i64,
+                           (bf16_t*)z_out, ldz, rows, n_embed);
     return seedmi_check_launch("vq_head_argmin");
 }

@@ -569,8 +569,8 @@ def test_vq_argmin_bit_exact(lib, golden_dir):
     z = torch.from_numpy(g["z"]).reshape(-1, 32)
     cb = torch.from_numpy(g["codebook"])
     gen = torch.Generator().manual_seed(5)
-    z_big = torch.cat([z, rand(gen, 1000, 32, scale=0.3)], 0)          # ragged row count (1128 rows)
-    for zz in (z, z_big):
+    z_big = torch.cat([z, rand(gen, 1000, 32, scale=0.3)], 0)          # ragged row count (1128 rows: the batch shape; 128 and 33 rows: the small-launch shape)
+    for zz in (z, z_big, z_big[95:128]):
         zd, cbd = bf(zz).cuda(), bf(cb).cuda()
         ee = torch.empty(cb.shape[0], dtype=torch.float32, device="cuda")
         ids = torch.full((zz.shape[0],), -1, dtype=torch.int64, device="cuda")
@@ -649,13 +649,15 @@ def test_vq_argmin_nonfinite_rows_follow_torch_argmin(mode, dtype):
         assert torch.equal(ids_s.cpu(), O.vq_argmin(z, e[:n_small], O.Prec(mode)))
 
 
-def test_vq_head_argmin_fused(lib):
+@pytest.mark.parametrize("rows", [1003, 37])
+def test_vq_head_argmin_fused(lib, rows):
     """seedmi_vq_head_argmin_bf16 (SURVEY 8a a13 -> a14): Linear(768, 32) + bias of encode_task_layer (qformer_quantizer.py:219-223) fused in
     front of the VQ sweep.  z equals the fp64 Linear rounded to half on all but a handful of round-to-nearest ties of the fp32 chain, and the
-    ids are EXACTLY the oracle's argmin of the z the kernel itself produced (ragged row count)."""
+    ids are EXACTLY the oracle's argmin of the z the kernel itself produced (ragged row count).  1003 rows take the batch shape of the sweep
+    (8 rows x 4 waves per workgroup), 37 the small-launch shape (1 row x 16 waves: one image is 32 rows)."""
     from oracle import seed_oracle as O
     gen = torch.Generator().manual_seed(21)
-    rows, hidden, n_embed = 1003, 768, 8192
+    hidden, n_embed = 768, 8192
     t = bf(torch.tanh(rand(gen, rows, hidden)))
     w = bf(rand(gen, 32, hidden, scale=0.05))
     b = bf(rand(gen, 32, scale=0.1))
@@ -675,7 +677,7 @@ def test_vq_head_argmin_fused(lib):
     zc = z.float().cpu()
     exact = (zc == want_z).float().mean().item()
     print(f"[vq head] z equal to the fp64 Linear rounded to half: {exact:.5f}")
-    assert exact > 0.995
+    assert exact > (0.995 if rows > 100 else 0.99)
     assert_close_bf16(z, want_z, "vq head z", atol_ulps=1.01, frac=1.0)
     want_ids = O.vq_argmin(zc, cb.float(), O.Prec("bf16"))
     assert torch.equal(ids.cpu(), want_ids)
