@@ -289,7 +289,17 @@ def tokenize_fp16_leg(cfg, device, images_bf16, codebook, ids_bf16, steps=3):
             "note": "agreement with the REFERENCE's own fp16 run on the golden images: profiles/r05_id_agreement_fp16.json (0.990; the bf16 build 0.930)"}
 
 
-def tokenize_latency_b1(eng, reps=50):
+def tokenizer_weight_bytes(cfg):
+    """16-bit bytes of every weight one tokenize pass reads (ViT + ln_vision + Q-Former + task head + codebook): 2.18 GB at full size."""
+    D, F, Q, FF = cfg.vit_dim, cfg.vit_ffn, cfg.qf_dim, cfg.qf_ffn
+    vit = cfg.vit_depth * (3 * D * D + D * D + 2 * D * F + 3 * D + D + F + D + 4 * D) + D * cfg.patch_k + D + cfg.n_tokens * D + D + 2 * D
+    n_cross = len([i for i in range(cfg.qf_layers) if i % cfg.cross_freq == 0])
+    qf = cfg.qf_layers * (4 * Q * Q + 4 * Q + 2 * Q + 2 * Q * FF + FF + Q + 2 * Q) + n_cross * (2 * Q * Q + 2 * Q * D + 4 * Q + 2 * Q) + cfg.n_query * Q + 2 * Q
+    head = Q * Q + Q + cfg.code_dim * Q + cfg.code_dim + cfg.n_embed * cfg.code_dim
+    return 2 * (vit + qf + head)
+
+
+def tokenize_latency_b1(eng, reps=50, weight_bytes=None):
     """The reference scripts' own call pattern (scripts/seed_tokenizer_inference.py:26-29): ONE image through encode_image.  Median of
     `reps` host-timed calls (launch + kernels + sync), and the same pass replayed from a hipGraph."""
     img = torch.randn(1, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)).bfloat16()
@@ -303,8 +313,13 @@ def tokenize_latency_b1(eng, reps=50):
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     ts.sort()
-    out = {"images": 1, "median_us": round(ts[len(ts) // 2] * 1e6, 1), "min_us": round(ts[0] * 1e6, 1), "reps": reps,
-           "timing": "host clock around encode() + synchronize"}
+    med = ts[len(ts) // 2]
+    wbytes = weight_bytes or 0
+    out = {"images": 1, "median_us": round(med * 1e6, 1), "min_us": round(ts[0] * 1e6, 1), "reps": reps,
+           "timing": "host clock around encode() + synchronize",
+           # one image must stream every weight once (2.18 GB at full size) and its 533.5 GFLOP are 0.21 ms of MFMA: the HBM roofline bounds it
+           "roofline": {"bound": "hbm", "bytes": wbytes, "achieved": round(wbytes / med / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(wbytes / med / 1e9 / HBM_PEAK_GBS, 4), "floor_us": round(wbytes / (HBM_PEAK_GBS * 1e9) * 1e6, 1)}}
     try:
         ids = eng.encode(img)
         gr = torch.cuda.CUDAGraph()
@@ -407,6 +422,73 @@ def _decode_traffic_ratio():
     return None
 
 
+def decode_per_kernel(eng, cfg, B, ctx):
+    """extra.llama_decode.per_kernel: the launches of ONE decode layer (+ the lm_head), each timed on its own in bursts over
+    the 32 layers' weights (a different layer per launch: every weight byte comes from HBM, as in the step) between two HIP events on the
+    launch stream - bytes, us and GB/s per launch.  The step's hipGraph replays exactly these launches back to back."""
+    import ctypes
+    from seed_amd import lib as L
+    lib = eng.lib
+    h, F, H, V = cfg.hidden, cfg.ffn, cfg.heads, cfg.vocab
+    hd, Mp = h // H, (B + 15) // 16 * 16
+    dev, dt = eng.device, eng.dtype
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, h, device=dev, generator=g).to(dt)
+    xn = torch.randn(Mp, h, device=dev, generator=g).to(dt)                      # fragment-major images (any values: timing only)
+    att, act = torch.randn(Mp, h, device=dev, generator=g).to(dt), torch.randn(Mp, F, device=dev, generator=g).to(dt)
+    qkv = torch.randn(B, 3 * h, device=dev, generator=g).to(dt)
+    logits = torch.empty(B, eng.vocab_pad, device=dev, dtype=dt)
+    sk = torch.empty(lib.seedmi_gemm_skinny_workspace_bytes(), dtype=torch.uint8, device=dev)
+    L.check(lib.seedmi_gemm_skinny_workspace_init(L.ptr(sk), sk.numel(), L.stream_ptr()), "skinny ws init")
+    EPS, nl = cfg.rms_eps, cfg.layers
+    scale = hd ** -0.5
+
+    def skinny(N, K, A, Wp, eps, res, epi, C, ldc, c_packed, xp):
+        return lib.seedmi_gemm_skinny_norm_ws_bf16(B, N, K, L.ptr(A), 1, Wp, eps, L.ptr(res) if res is not None else None, h if res is not None else 0,
+                                                   epi, L.ptr(C), ldc, c_packed, L.ptr(xp) if xp is not None else None, L.ptr(sk), sk.numel(), L.stream_ptr())
+    launches = {
+        "q/k/v": (lambda l: skinny(3 * h, h, xn, eng._layers[l].qkv_wp, EPS, None, L.EPI_NONE, qkv, 3 * h, 0, None), 3 * h * h * 2),
+        "attention (RoPE + append fused)": (lambda l: lib.seedmi_llama_decode_attention_bf16(
+            L.ptr(qkv), 3 * h, None, eng.w.cos_t, eng.w.sin_t, eng._layers[l].k_cache, eng._layers[l].v_cache, L.ptr(att), h, B, H, hd, eng.tmax, ctx,
+            scale, 1, None, cfg.max_pos, L.stream_ptr()), 2 * B * (ctx + 1) * h * 2),
+        "o_proj + residual": (lambda l: skinny(h, h, att, eng._layers[l].o_wp, 0.0, x, L.EPI_BIAS_RESIDUAL, x, h, 0, xn), h * h * 2),
+        "gate/up + SwiGLU": (lambda l: skinny(2 * F, h, xn, eng._layers[l].gate_up_wp, EPS, None, L.EPI_SWIGLU, act, F, 1, None), 2 * F * h * 2),
+        "down + residual": (lambda l: skinny(h, F, act, eng._layers[l].down_wp, 0.0, x, L.EPI_BIAS_RESIDUAL, x, h, 0, xn), F * h * 2),
+    }
+    out, layer_us = {}, 0.0
+    for name, (fn, nbytes) in launches.items():
+        for l in range(nl):
+            L.check(fn(l), name)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for l in range(nl):
+                fn(l)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / nl * 1e3)
+        us = sorted(ts)[2]
+        layer_us += us
+        out[name] = {"bytes": nbytes, "us": round(us, 2), "gbps": round(nbytes / us / 1e3, 1)}
+    fn = lambda: skinny(V, h, xn, eng.w.lm_head_p, EPS, None, L.EPI_NONE, logits, eng.vocab_pad, 0, None)      # noqa: E731
+    for _ in range(3):
+        L.check(fn(), "lm_head")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    out["lm_head (weights stay in the Infinity Cache between these launches)"] = {"bytes": V * h * 2, "us": round(us, 2), "gbps": round(V * h * 2 / us / 1e3, 1)}
+    L.check(lib.seedmi_gemm_skinny_ws_status(L.ptr(sk), sk.numel(), L.stream_ptr()), "skinny ws status")
+    return {"batch": B, "context": ctx, "launches": out, "layer_sum_us": round(layer_us, 2),
+            "timing": "bursts of 32 launches (one per layer's weights) between two HIP events on the launch stream; median of 5"}
+
+
 def llama_decode_leg(B, n_new):
     """SEED-LLaMA-8B (Vicuna-7B body, vocab 40194): image -> 32 tokens -> greedy decode, batch B, bf16."""
     from seed_amd import config as C
@@ -460,7 +542,12 @@ def llama_decode_leg(B, n_new):
               "hbm_frac": round(w_bytes / dt1 / 1e9 / HBM_PEAK_GBS, 4), "graph_nodes_per_step": "one hipGraph replay per token"}
     except Exception as e:
         b1 = {"error": repr(e)[:200]}
+    try:
+        per_kernel = decode_per_kernel(eng, cfg, B, ctx_mid)
+    except Exception as e:
+        per_kernel = {"error": repr(e)[:300]}
     return {"metric": "tokens/s SEED-LLaMA-8B greedy decode", "value": round(tok_s, 1), "batch": B, "new_tokens": n_new, "latency_b1": b1,
+            "per_kernel": per_kernel,
             "ms_per_step": round(dt / steps * 1e3, 3), "prefill_ms": round(t_prefill * 1e3, 2), "prompt_len": T0,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_step": bytes_step,
@@ -668,7 +755,7 @@ def main():
         # the dominant kernel is local to a GPU: rank 0 times it at every N (outside the timed region); the CPU baseline
         # is an N = 1 leg only
         try:
-            extra["latency_b1"] = {"tokenize": tokenize_latency_b1(eng)}
+            extra["latency_b1"] = {"tokenize": tokenize_latency_b1(eng, weight_bytes=tokenizer_weight_bytes(cfg))}
         except Exception as e:
             extra["latency_b1"] = {"tokenize": {"error": repr(e)[:200]}}
         if world == 1 and not args.no_fp16:
