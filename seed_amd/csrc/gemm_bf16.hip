@@ -909,6 +909,113 @@ __global__ __launch_bounds__(PROD ? 512 : 256, NS <= 4 ? 2 : 1) void gemm64_kern
 }
 
 // ======================================================================================================
+// Kernel "gemms": the small-M kernel in three tile shapes with EIGHT producer waves (round 6).  What bounds one image's GEMMs is not
+// memory latency (average L2 round trip 420 cycles, profiles/r06_pmc_stalls_b1_*.json) and not the consumers (double-buffered fragment
+// reads changed nothing) but the rate at which a CU's waves can ISSUE operand requests: a wave gets one 1 KiB LDS-DMA request accepted per
+// ~100 cycles, so gemm64's four producers move a 16 KiB K-tile in ~400 cycles where the L1 -> LDS path (64 B per clock) needs 256
+// (tools/probes/operand_feed_probe.hip: 4 waves 74 GB/s per CU, 8 waves 104, 16 waves 124).  And 64x64 tiles put 330 (QKV) / 480 (fc1)
+// tiles on 256 CUs: the CUs that get two decide the launch.  So: 8 producer waves, one workgroup per CU, and per GEMM the shape whose
+// worst CU moves the fewest bytes - 64x64 (CM = 4, CN = 1), 128x64 (8, 1: QKV at M = 257 is 198 tiles) or 64x128 (4, 2: fc1 240 tiles).
+// Consumer wave = 16 rows x 64 columns exactly as in gemm64 (same fragment layout, same k-ordered chain, same epilogue): bit-identical.
+template <int EPI, bool LNF, int CM, int CN>
+__global__ __launch_bounds__(64 * (CM * CN + 8), 1) void gemms_kernel(GemmParams p) {
+    constexpr int TM = 16 * CM, TN = 64 * CN, NC = CM * CN, PW = 8;
+    constexpr int A_BYTES = TM * BK * 2, W_BYTES = TN * BK * 2, ST = A_BYTES + W_BYTES;     // one ring stage: A tile | W tile, 128-byte rows
+    constexpr int PA = TM / 8, PN = TN / 8, PP = (PA + PN) / PW;                            // 1 KiB pieces (8 rows) per stage / per producer
+    static_assert((PA + PN) % PW == 0 && PA % PW == 0, "pieces deal evenly over the producers");
+    // A ring slot holds KPS = 2 consecutive K-tiles and there is ONE barrier per slot: what paces one image's K loop is the barrier round
+    // trip itself (~400 cycles per K-tile whether four or eight producers feed it and whether or not the consumers double-buffer their
+    // fragments), so a slot carries twice the MFMAs per barrier.
+    constexpr int KPS = 2, SLOT = KPS * ST;
+    constexpr int NS = SLOT <= 32768 ? 4 : 3;                                                 // 128 KiB / 144 KiB of ring
+    constexpr int NT = 64 * (NC + PW);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= NC;
+    const int li = lane & 15, g = lane >> 4;
+    int tm, tn;
+    {   // m-tiles fastest, XCD-contiguous (see gemm64_kernel)
+        const int nt = p.tiles_m * p.tiles_n, bid = (int)blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tm = t % p.tiles_m;
+        tn = t / p.tiles_m;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+    if (EPI == EPI_BIAS_GELU && GELU_BY_TABLE) load_gelu_lut(smem + NS * SLOT, tid, NT);    // (the K loop's barriers order it before the epilogue)
+    const char* lut = (EPI == EPI_BIAS_GELU) ? smem + NS * SLOT : nullptr;
+    const int nk = p.K / BK, nslots = (nk + KPS - 1) / KPS;
+    if (producer) {
+        const int pw = wave - NC;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, -1, 0x00020000);
+        uint32_t off[PP];
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {                 // piece pw + 8 j of [A pieces | W pieces]: rows 8 i .. 8 i + 7 of that operand's tile
+            const bool isA = PW * j < PA;
+            const int i = isA ? pw + PW * j : pw + PW * j - PA;
+            const int row = 8 * i + (lane >> 3), cs = lane & 7;
+            off[j] = isA ? 2u * ((uint32_t)min(m0 + row, p.M - 1) * (uint32_t)p.lda + 8u * (uint32_t)(cs ^ swzA(row)))
+                         : 2u * ((uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldw + 8u * (uint32_t)(cs ^ swzW(row)));
+        }
+        auto stage = [&](int sl) {                     // K-tiles min(KPS sl + u, nk - 1) into ring slot sl % NS (position-free: the tail re-fetches the last one)
+            char* base = smem + (sl % NS) * SLOT;
+#pragma unroll
+            for (int u = 0; u < KPS; ++u) {
+                const uint32_t koff = 2u * (uint32_t)(min(KPS * sl + u, nk - 1) * BK);
+#pragma unroll
+                for (int j = 0; j < PP; ++j) {
+                    const bool isA = PW * j < PA;
+                    glds16_buf(isA ? rsA : rsW, off[j], koff, base + u * ST + (isA ? (pw + PW * j) * 1024 : A_BYTES + (pw + PW * j - PA) * 1024));
+                }
+            }
+        };
+#pragma unroll
+        for (int sl = 0; sl < NS - 1; ++sl) stage(sl);
+        for (int sl = 0; sl < nslots; ++sl) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPS * PP * (NS - 2)) : "memory");     // the oldest slot in flight has landed
+            __builtin_amdgcn_s_barrier();             // slot sl published; the consumers have retired their reads of slot sl - 1
+            stage(sl + NS - 1);                       // into the ring position of slot sl - 1
+        }
+        return;                                       // (the epilogue has no barrier; requests still in flight target ring slots only)
+    }
+    const int wm = wave % CM, wn = wave / CM;
+    // fragment read addresses inside a stage (k-step 0; k-step 1 = ^64)
+    const int ra = 16 * wm + li;
+    const int rdA = ra * 128 + ((g ^ swzA(ra)) << 4);
+    int rdW[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rw = 64 * wn + 16 * (li >> 2) + 4 * t + (li & 3);
+        rdW[t] = A_BYTES + rw * 128 + ((g ^ swzW(rw)) << 4);
+    }
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < nslots; ++sl) {
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int u = 0; u < KPS; ++u) {
+            if (u > 0 && KPS * sl + u >= nk) break;                // odd K-tile count: the last slot's second half is a re-fetch, not a K-tile (uniform)
+            const char* sb = smem + (sl % NS) * SLOT + u * ST;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a, w[4];
+                a = *(const bf16x8*)(sb + (rdA ^ (ks << 6)));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w[t] = *(const bf16x8*)(sb + (rdW[t] ^ (ks << 6)));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[0][ni] = seedmi_mfma_16x16x32(w[ni], a, acc[0][ni]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the fragments are in registers before the next barrier lets the slot be restaged)
+    }
+    gemm_epilogue<EPI, 1, true, NoHook, LNF>(p, acc, m0 + 16 * wm, n0 + 64 * wn + 16 * g, li, lut);
+}
+
+// ======================================================================================================
 // Kernel "gemm256": 256x256x64 block tile, 8 waves (2 along M x 4 along N), 128x64 per wave.
 //
 // Deep-pipelined schedule for one workgroup per CU (128 KiB LDS, 2 waves per SIMD):
@@ -2095,6 +2202,43 @@ int launch_gemm64_ns(GemmParams p, hipStream_t stream) {
     hipLaunchKernelGGL((gemm64_kernel<EPI, LNF, NS, PROD>), dim3(p.tiles_m * p.tiles_n), dim3(PROD ? 512 : 256), lds, stream, p);
     return seedmi_check_launch("gemm64");
 }
+template <int EPI, bool LNF, int CM, int CN>
+int launch_gemms_shape(GemmParams p, hipStream_t stream) {
+    constexpr int TM = 16 * CM, TN = 64 * CN, SLOT = 2 * (TM + TN) * BK * 2, NS = SLOT <= 32768 ? 4 : 3;
+    constexpr int lds = NS * SLOT + (EPI == EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget of the shaped small-M kernel");
+    p.tiles_m = (p.M + TM - 1) / TM;
+    p.tiles_n = (p.N + TN - 1) / TN;
+    static bool attr_set[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemms_kernel<EPI, LNF, CM, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemms_kernel<EPI, LNF, CM, CN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * (CM * CN + 8)), lds, stream, p);
+    return seedmi_check_launch("gemms");
+}
+// The shape whose busiest CU streams the fewest operand bytes (what bounds a small-M launch): ceil(tiles / CUs) x (TM + TN) rows of K.
+// `force`: 66 / 67 / 68 = 64x64 / 128x64 / 64x128 ("gemm" option, tests and A/B)
+template <int EPI, bool LNF = false>
+int launch_gemms(const GemmParams& p, hipStream_t stream, int force) {
+    const int cus = device_cus(current_device());
+    auto cost = [&](int TM, int TN) {
+        const long long tiles = (long long)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
+        return ((tiles + cus - 1) / cus) * (TM + TN);
+    };
+    int pick = force;
+    if (pick < 66 || pick > 68) {
+        const long long c64 = cost(64, 64), c128m = cost(128, 64), c128n = cost(64, 128);
+        pick = 66;
+        if (c128m < c64 && c128m <= c128n) pick = 67;
+        else if (c128n < c64 && c128n < c128m) pick = 68;
+    }
+    if (pick == 67) return launch_gemms_shape<EPI, LNF, 8, 1>(p, stream);
+    if (pick == 68) return launch_gemms_shape<EPI, LNF, 4, 2>(p, stream);
+    return launch_gemms_shape<EPI, LNF, 4, 1>(p, stream);
+}
+
 template <int EPI, bool LNF = false>
 int launch_gemm64(GemmParams p, hipStream_t stream) {
     p.tiles_m = (p.M + 63) / 64;
@@ -2132,7 +2276,13 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
     // small M (one image: M = 257; a short prompt): when 128x128 tiles cannot give every CU a workgroup, the 64x64 kernel's four times
     // finer tiling and deep ring do (same bits)
     const long long tiles128 = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    const bool small = variant == 64 || variant == 65 || (variant == 0 && g_gemm_small && tiles128 < device_cus(current_device()));
+    const bool small = variant == 64 || variant == 65 || (variant >= 66 && variant <= 69) ||
+                       (variant == 0 && g_gemm_small && tiles128 < device_cus(current_device()));
+    // the shaped kernel (one 12- or 16-wave workgroup per CU) where a launch is a round or two of tiles - measured faster up to four images
+    // (M = 1028: 6.22 vs 6.40 ms per pass), slower at eight (10.1 vs 9.7: its rounds run one after the other, gemm64's two 8-wave workgroups
+    // per CU overlap each other's prologue and epilogue) - and gemm64 beyond
+    constexpr int SHAPED_MAX_M = 1100;
+    if (small && variant != 64 && variant != 65 && ((g_gemm_small == 1 && p.M <= SHAPED_MAX_M) || variant >= 66)) return launch_gemms<EPI, LNF>(p, s, variant);
     return small ? launch_gemm64<EPI, LNF>(p, s) : launch_gemm128<EPI, LNF>(p, s);
 }
 
@@ -2154,7 +2304,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
 #else
     const bool dev_variant = false;
 #endif
-    if (key && !strcmp(key, "gemm") && (value == 0 || value == 64 || value == 65 || value == 128 || value == 256 || dev_variant)) {
+    if (key && !strcmp(key, "gemm") && (value == 0 || (value >= 64 && value <= 69) || value == 128 || value == 256 || dev_variant)) {
         g_gemm_variant = value;
         g_gemm64_prod = value != 65;
         return SEEDMI_OK;
@@ -2175,7 +2325,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
         return SEEDMI_OK;
     }
 #endif
-    if (key && !strcmp(key, "gemm_small") && (value == 0 || value == 1)) {
+    if (key && !strcmp(key, "gemm_small") && (value == 0 || value == 1 || value == 2)) {       // 2: the round-5 64x64 kernel (gemm64) instead of the shaped one
         g_gemm_small = value;
         return SEEDMI_OK;
     }

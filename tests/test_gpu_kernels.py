@@ -69,8 +69,9 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[64, 65, 128, 256, (256, 0), (256, 24657), (256, 57425)],
-                ids=["gemm64", "gemm64_4wave", "gemm128", "gemm256", "gemm256_sched0", "gemm256_seam", "gemm256_peel"])
+@pytest.fixture(params=[64, 65, 66, 67, 68, 128, 256, (256, 0), (256, 24657), (256, 57425)],
+                ids=["gemm64", "gemm64_4wave", "gemms_64x64", "gemms_128x64", "gemms_64x128", "gemm128", "gemm256", "gemm256_sched0", "gemm256_seam",
+                     "gemm256_peel"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (64x64 deep-ring small-M kernel, 128x128 two-barrier and 256x256 staggered deep pipeline), the 256x256 kernel
     under its default schedule (gemm_sched 8273: two-phase K-tile, position-free body, round 4), under the round-2 schedule (0) and
@@ -110,6 +111,30 @@ def test_gemm_bias(lib, gemm_variant, M, N, K):
     assert_close_bf16(C[:, :N], want, f"gemm_bias {M}x{N}x{K}")
     if ldc > N:
         assert (C[:, N:] == 0).all(), "wrote past N"
+
+
+@pytest.mark.parametrize("M", [257, 514, 40])
+def test_small_m_kernels_are_bit_identical(lib, M):
+    """One image is M = 257: the library then picks, per GEMM, the shape of the small-M kernel whose busiest CU streams the fewest bytes
+    (64x64 / 128x64 / 64x128 tiles, eight producer waves: round 6).  Whatever it picks - and whatever a batch of 256 takes (the 128x128 and
+    256x256 kernels) - every output element is the same k-ordered MFMA chain: all kernels bit-equal on the four ViT GEMM shapes with the
+    epilogues the path uses (an image alone must give the ids it gives inside a batch)."""
+    gen = torch.Generator().manual_seed(900 + M)
+    D, F = 1408, 6144
+    for name, N, K, epi in (("qkv", 3 * D, D, L.EPI_BIAS), ("proj", D, D, L.EPI_BIAS_RESIDUAL), ("fc1", F, D, L.EPI_BIAS_GELU), ("fc2", D, F, L.EPI_BIAS_RESIDUAL)):
+        A = bf(rand(gen, M, K)).cuda()
+        W = bf(rand(gen, N, K, scale=0.03)).cuda()
+        bias = bf(rand(gen, N, scale=0.1)).cuda()
+        R = bf(rand(gen, M, N)).cuda() if epi == L.EPI_BIAS_RESIDUAL else None
+        outs = {}
+        try:
+            for v in (0, 64, 66, 67, 68, 128, 256):
+                L.check(lib.seedmi_set_option(b"gemm", v), "set_option")
+                outs[v] = run_gemm(lib, A, W, bias, R, epi)
+        finally:
+            lib.seedmi_set_option(b"gemm", 0)
+        for v, C in outs.items():
+            assert torch.equal(C.view(torch.int16), outs[128].view(torch.int16)), f"{name} M={M}: kernel {v} differs from the 128x128 kernel in {(C != outs[128]).sum().item()} values"
 
 
 def test_gemm_identity_layout(lib, gemm_variant):

@@ -20,7 +20,8 @@ for P in \
   "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum" \
   "TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_TAG_STALL_sum" \
   "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TCP_LATENCY_sum" \
-  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_LEVEL_sum TCC_BUBBLE_sum"; do
+  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_LEVEL_sum TCC_BUBBLE_sum" \
+  "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_WRREQ_WRITE_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum"; do
   i=$((i+1))
   timeout 180 rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pmcs_p$i -- $CMD > /tmp/pmcs_p$i.log 2>&1 || { echo "pass $i ($P) failed:"; tail -3 /tmp/pmcs_p$i.log; }
 done
@@ -56,7 +57,14 @@ if out.get("TCC_HIT_sum") is not None and out.get("TCC_MISS_sum") is not None an
     d["l2_hit_rate"] = out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"])
 if out.get("TCC_EA0_RDREQ_sum"):
     d["ea_read_requests_to_dram_share"] = out.get("TCC_EA0_RDREQ_DRAM_sum", 0) / out["TCC_EA0_RDREQ_sum"]
-    d["ea_read_bytes"] = (out["TCC_EA0_RDREQ_sum"] - out.get("TCC_EA0_RDREQ_32B_sum", 0)) * 64 + out.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
+    if out.get("TCC_EA0_RDREQ_128B_sum") is not None:       # exact: requests by size (the 64 B per request of FETCH_SIZE undercounts 128-byte requests)
+        n128, n64 = out.get("TCC_EA0_RDREQ_128B_sum", 0), out.get("TCC_EA0_RDREQ_64B_sum", 0)
+        n32 = out.get("TCC_EA0_RDREQ_32B_sum", 0)
+        d["ea_read_bytes"] = 128 * n128 + 64 * n64 + 32 * n32 + 64 * max(out["TCC_EA0_RDREQ_sum"] - n128 - n64 - n32, 0)
+        d["ea_read_requests_by_size"] = {"128B": n128, "64B": n64, "32B": n32, "all": out["TCC_EA0_RDREQ_sum"]}
+    else:
+        d["ea_read_bytes"] = (out["TCC_EA0_RDREQ_sum"] - out.get("TCC_EA0_RDREQ_32B_sum", 0)) * 64 + out.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
+    d["ea_write_bytes"] = 64 * out.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * max(out.get("TCC_EA0_WRREQ_sum", 0) - out.get("TCC_EA0_WRREQ_64B_sum", 0), 0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(d, open("gpurun_out/" + os.environ["OUT"], "w"), indent=1)
 print(json.dumps(d, indent=1))
