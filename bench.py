@@ -121,7 +121,7 @@ def qkv_gemm_roofline(batch):
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    for name in ("r05_pmc_qkv_gemm256.json", "r04_pmc_qkv_gemm256.json", "r03_pmc_qkv_gemm256.json", "r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
+    for name in ("r06_pmc_qkv_gemm256.json", "r05_pmc_qkv_gemm256.json", "r04_pmc_qkv_gemm256.json", "r03_pmc_qkv_gemm256.json", "r02_pmc_qkv_gemm256.json", "r01_pmc_qkv_gemm256.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if batch == 256 and os.path.exists(pmc):
             # bytes past the L2s per launch from rocprofv3 --pmc passes of this same kernel/shape (tools/pmc_qkv.sh: PMC counters
@@ -131,6 +131,7 @@ def qkv_gemm_roofline(batch):
             traffic = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
             traffic_src = "profiles/" + name + " (rocprofv3 --pmc passes of this launch, tools/pmc_qkv.sh; NOT measured in this run)"
             break
+    # measured live beside it: the MFMA-only loop of THIS box (the power-limited ceiling the 2.5 PF datasheet figure sits above)
     return {"bound": "mfma", "kernel": "gemm256_kernel<BIAS, LayerNorm fold, schedule 8273 (two-phase K-tile, position-free body)>, persistent (ViT norm1 + QKV: M=%d K=%d N=%d)" % (M, K, N),
             "launch": "BASELINE-defined M = batch * 257 = %d launch (the tokenize path issues 2 x M = %d on two streams: in_path_launch)" % (M, Mh),
             "in_path_launch": {"M": Mh, "avg_launch_ms": round(half_ms, 4), "achieved": round(2.0 * Mh * N * K / (half_ms * 1e-3) / 1e12, 1),
@@ -139,6 +140,11 @@ def qkv_gemm_roofline(batch):
             "with_streamk_tail": {"avg_launch_ms": round(sk_avg_ms, 4), "achieved": round(flops / (sk_avg_ms * 1e-3) / 1e12, 1)},
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            # what the traffic figure means for the bound (profiles/r06_pmc_stalls_qkv_gemm256.json: memory-side requests counted by size -
+            # 99.98 % of the reads are 128-byte requests, i.e. 1.356 GB, the writes are exactly C's 0.556 GB - and
+            # profiles/r06_infinity_cache_eviction_ab.json: the launch takes the same time with its operands evicted from the Infinity Cache)
+            "traffic_note": "1.91 GB past the L2s in 0.63 ms = 3.0 TB/s, under half of what HBM streams; the launch is as fast behind a 1 GiB eviction "
+                            "sweep as with A and W resident in the Infinity Cache: the operand stream does not bound it",
             "algorithmic_bytes": 2.0 * (M * K + N * K + M * N),
             "flops_per_launch": flops, "avg_launch_ms": round(avg_ms, 4), "median_launch_ms": round(med_ms, 4)}
 

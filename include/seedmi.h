@@ -66,9 +66,9 @@ int seedmi_check_device(void);
  * exist only in the -DSEEDMI_DEVTOOLS build (libseedmi_dev.so, used by tools/).  Unknown keys or values return SEEDMI_E_SHAPE.
  *
  *   key                    values (default first)        what it selects
- * = gemm                   0 | 64 | 65 | 66..69 | 128 | 256   tile kernel: by shape | 64x64 deep-ring small-M kernel (65: its four-wave form without
- *                                                        producer waves) | shaped small-M kernel with eight producer waves: 64x64 / 128x64 /
- *                                                        64x128 tiles / the shape by cost | 128x128 | persistent 256x256
+ * = gemm                   0 | 64 | 65 | 66..70 | 128 | 256   tile kernel: by shape | 64x64 deep-ring small-M kernel (65: its four-wave form without
+ *                                                        producer waves) | shaped small-M kernel with dedicated producer waves: 64x64 / 128x64 /
+ *                                                        64x128 tiles / the shape by cost / 32x64 | 128x128 | persistent 256x256
  * = gemm_small             1 | 2 | 0                     small M (128x128 tiles cannot give every CU a workgroup; one image: M = 257): the shaped
  *                                                        kernel up to M = 1100, the 64x64 kernel beyond | always the 64x64 kernel | neither
  * = gemm64_xcd             1 | 0                         64x64 kernel: XCD-contiguous tile order (the m-tiles sharing a W panel on one XCD) |

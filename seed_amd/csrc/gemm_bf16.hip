@@ -915,11 +915,12 @@ __global__ __launch_bounds__(PROD ? 512 : 256, NS <= 4 ? 2 : 1) void gemm64_kern
 // ~100 cycles, so gemm64's four producers move a 16 KiB K-tile in ~400 cycles where the L1 -> LDS path (64 B per clock) needs 256
 // (tools/probes/operand_feed_probe.hip: 4 waves 74 GB/s per CU, 8 waves 104, 16 waves 124).  And 64x64 tiles put 330 (QKV) / 480 (fc1)
 // tiles on 256 CUs: the CUs that get two decide the launch.  So: 8 producer waves, one workgroup per CU, and per GEMM the shape whose
-// worst CU moves the fewest bytes - 64x64 (CM = 4, CN = 1), 128x64 (8, 1: QKV at M = 257 is 198 tiles) or 64x128 (4, 2: fc1 240 tiles).
+// worst CU moves the fewest bytes - 64x64 (CM = 4, CN = 1), 128x64 (8, 1: QKV at M = 257 is 198 tiles), 64x128 (4, 2: fc1 240 tiles) or
+// 32x64 (2, 1 with four producers: proj / fc2 at M = 257 are 110 tiles of 64x64 - 146 CUs idle - and 198 of 32x64).
 // Consumer wave = 16 rows x 64 columns exactly as in gemm64 (same fragment layout, same k-ordered chain, same epilogue): bit-identical.
-template <int EPI, bool LNF, int CM, int CN>
-__global__ __launch_bounds__(64 * (CM * CN + 8), 1) void gemms_kernel(GemmParams p) {
-    constexpr int TM = 16 * CM, TN = 64 * CN, NC = CM * CN, PW = 8;
+template <int EPI, bool LNF, int CM, int CN, int PW>
+__global__ __launch_bounds__(64 * (CM * CN + PW), 1) void gemms_kernel(GemmParams p) {
+    constexpr int TM = 16 * CM, TN = 64 * CN, NC = CM * CN;
     constexpr int A_BYTES = TM * BK * 2, W_BYTES = TN * BK * 2, ST = A_BYTES + W_BYTES;     // one ring stage: A tile | W tile, 128-byte rows
     constexpr int PA = TM / 8, PN = TN / 8, PP = (PA + PN) / PW;                            // 1 KiB pieces (8 rows) per stage / per producer
     static_assert((PA + PN) % PW == 0 && PA % PW == 0, "pieces deal evenly over the producers");
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(64 * (CM * CN + 8), 1) void gemms_kernel(GemmParams
     // trip itself (~400 cycles per K-tile whether four or eight producers feed it and whether or not the consumers double-buffer their
     // fragments), so a slot carries twice the MFMAs per barrier.
     constexpr int KPS = 2, SLOT = KPS * ST;
-    constexpr int NS = SLOT <= 32768 ? 4 : 3;                                                 // 128 KiB / 144 KiB of ring
+    constexpr int NS = SLOT <= 24576 ? 5 : SLOT <= 32768 ? 4 : 3;                             // 120 / 128 / 144 KiB of ring
     constexpr int NT = 64 * (NC + PW);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -2202,9 +2203,9 @@ int launch_gemm64_ns(GemmParams p, hipStream_t stream) {
     hipLaunchKernelGGL((gemm64_kernel<EPI, LNF, NS, PROD>), dim3(p.tiles_m * p.tiles_n), dim3(PROD ? 512 : 256), lds, stream, p);
     return seedmi_check_launch("gemm64");
 }
-template <int EPI, bool LNF, int CM, int CN>
+template <int EPI, bool LNF, int CM, int CN, int PW = 8>
 int launch_gemms_shape(GemmParams p, hipStream_t stream) {
-    constexpr int TM = 16 * CM, TN = 64 * CN, SLOT = 2 * (TM + TN) * BK * 2, NS = SLOT <= 32768 ? 4 : 3;
+    constexpr int TM = 16 * CM, TN = 64 * CN, SLOT = 2 * (TM + TN) * BK * 2, NS = SLOT <= 24576 ? 5 : SLOT <= 32768 ? 4 : 3;
     constexpr int lds = NS * SLOT + (EPI == EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
     static_assert(lds <= 160 * 1024, "LDS budget of the shaped small-M kernel");
     p.tiles_m = (p.M + TM - 1) / TM;
@@ -2212,14 +2213,14 @@ int launch_gemms_shape(GemmParams p, hipStream_t stream) {
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemms_kernel<EPI, LNF, CM, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemms_kernel<EPI, LNF, CM, CN, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemms_kernel<EPI, LNF, CM, CN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * (CM * CN + 8)), lds, stream, p);
+    hipLaunchKernelGGL((gemms_kernel<EPI, LNF, CM, CN, PW>), dim3(p.tiles_m * p.tiles_n), dim3(64 * (CM * CN + PW)), lds, stream, p);
     return seedmi_check_launch("gemms");
 }
 // The shape whose busiest CU streams the fewest operand bytes (what bounds a small-M launch): ceil(tiles / CUs) x (TM + TN) rows of K.
-// `force`: 66 / 67 / 68 = 64x64 / 128x64 / 64x128 ("gemm" option, tests and A/B)
+// `force`: 66 / 67 / 68 / 70 = 64x64 / 128x64 / 64x128 / 32x64 ("gemm" option, tests and A/B); 69 = by cost
 template <int EPI, bool LNF = false>
 int launch_gemms(const GemmParams& p, hipStream_t stream, int force) {
     const int cus = device_cus(current_device());
@@ -2228,14 +2229,17 @@ int launch_gemms(const GemmParams& p, hipStream_t stream, int force) {
         return ((tiles + cus - 1) / cus) * (TM + TN);
     };
     int pick = force;
-    if (pick < 66 || pick > 68) {
-        const long long c64 = cost(64, 64), c128m = cost(128, 64), c128n = cost(64, 128);
-        pick = 66;
-        if (c128m < c64 && c128m <= c128n) pick = 67;
-        else if (c128n < c64 && c128n < c128m) pick = 68;
+    if (pick != 66 && pick != 67 && pick != 68 && pick != 70) {
+        const long long c[4] = {cost(64, 64), cost(128, 64), cost(64, 128), cost(32, 64)};
+        const int id[4] = {66, 67, 68, 70};
+        int best = 0;
+        for (int i = 1; i < 4; ++i)
+            if (c[i] < c[best]) best = i;
+        pick = id[best];
     }
     if (pick == 67) return launch_gemms_shape<EPI, LNF, 8, 1>(p, stream);
     if (pick == 68) return launch_gemms_shape<EPI, LNF, 4, 2>(p, stream);
+    if (pick == 70) return launch_gemms_shape<EPI, LNF, 2, 1, 4>(p, stream);
     return launch_gemms_shape<EPI, LNF, 4, 1>(p, stream);
 }
 
@@ -2276,7 +2280,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s, void* sk_ws, size_t sk_ws_by
     // small M (one image: M = 257; a short prompt): when 128x128 tiles cannot give every CU a workgroup, the 64x64 kernel's four times
     // finer tiling and deep ring do (same bits)
     const long long tiles128 = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    const bool small = variant == 64 || variant == 65 || (variant >= 66 && variant <= 69) ||
+    const bool small = variant == 64 || variant == 65 || (variant >= 66 && variant <= 70) ||
                        (variant == 0 && g_gemm_small && tiles128 < device_cus(current_device()));
     // the shaped kernel (one 12- or 16-wave workgroup per CU) where a launch is a round or two of tiles - measured faster up to four images
     // (M = 1028: 6.22 vs 6.40 ms per pass), slower at eight (10.1 vs 9.7: its rounds run one after the other, gemm64's two 8-wave workgroups
@@ -2304,7 +2308,7 @@ extern "C" int seedmi_set_option(const char* key, int value) {
 #else
     const bool dev_variant = false;
 #endif
-    if (key && !strcmp(key, "gemm") && (value == 0 || (value >= 64 && value <= 69) || value == 128 || value == 256 || dev_variant)) {
+    if (key && !strcmp(key, "gemm") && (value == 0 || (value >= 64 && value <= 70) || value == 128 || value == 256 || dev_variant)) {
         g_gemm_variant = value;
         g_gemm64_prod = value != 65;
         return SEEDMI_OK;

@@ -69,9 +69,9 @@ def run_gemm(lib, A, W, bias, res, epi, out_rows=None, out_cols=None, row_group=
     return C
 
 
-@pytest.fixture(params=[64, 65, 66, 67, 68, 128, 256, (256, 0), (256, 24657), (256, 57425)],
-                ids=["gemm64", "gemm64_4wave", "gemms_64x64", "gemms_128x64", "gemms_64x128", "gemm128", "gemm256", "gemm256_sched0", "gemm256_seam",
-                     "gemm256_peel"])
+@pytest.fixture(params=[64, 65, 66, 67, 68, 70, 128, 256, (256, 0), (256, 24657), (256, 57425)],
+                ids=["gemm64", "gemm64_4wave", "gemms_64x64", "gemms_128x64", "gemms_64x128", "gemms_32x64", "gemm128", "gemm256", "gemm256_sched0",
+                     "gemm256_seam", "gemm256_peel"])
 def gemm_variant(request, lib):
     """Every GEMM parity test runs once per tile kernel (64x64 deep-ring small-M kernel, 128x128 two-barrier and 256x256 staggered deep pipeline), the 256x256 kernel
     under its default schedule (gemm_sched 8273: two-phase K-tile, position-free body, round 4), under the round-2 schedule (0) and
@@ -128,7 +128,7 @@ def test_small_m_kernels_are_bit_identical(lib, M):
         R = bf(rand(gen, M, N)).cuda() if epi == L.EPI_BIAS_RESIDUAL else None
         outs = {}
         try:
-            for v in (0, 64, 66, 67, 68, 128, 256):
+            for v in (0, 64, 66, 67, 68, 70, 128, 256):
                 L.check(lib.seedmi_set_option(b"gemm", v), "set_option")
                 outs[v] = run_gemm(lib, A, W, bias, R, epi)
         finally:
