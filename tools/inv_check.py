@@ -1,3 +1,8 @@
+#!/usr/bin/env python
+"""Batch invariance in ten seconds (MID config): 40 images in one call, as 4 x 10 and as singles must give identical ids under every
+option set that only chooses between kernels (the 64x64 kernel's tile order, the LayerNorm fold on / off).  The quick check behind every
+small-M kernel edit of round 6 (the full statement is tests/test_gpu_tokenizer.py::test_batch_independence_and_raggedness and
+test_full_size_batch256_properties)."""
 import sys, torch
 sys.path.insert(0, '.')
 from seed_amd import config as C, lib as L

@@ -22,7 +22,7 @@ sd = make_tokenizer_state_dict(C.SEED2, seed=0, device="cuda")
 eng = TokenizerEngine(sd, C.SEED2, device="cuda", dtype=DTYPE)
 del sd
 img = torch.randn(B, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)).to(DTYPE)
-defaults = {"tokenize_streams": 2, "tokenize_streamk": 0, "gemm": 0, "gemm_sched": -1, "attn_vit": 5, "attn_xcd": 1, "attn_store_wait": 1, "gemm_group_m": 0, "gemm_prefetch_residual": 0, "gemm_residual_nt": 1, "tokenize_lnfold": 1, "tokenize_split_rounds": 0, "tokenize_vq_head": 1, "tokenize_tile_stats": 0, "gemm_store": 128}
+defaults = {"tokenize_streams": 2, "tokenize_streamk": 0, "gemm": 0, "gemm_sched": -1, "attn_vit": 5, "attn_xcd": 1, "attn_store_wait": 1, "gemm_group_m": 0, "gemm_prefetch_residual": 0, "gemm_residual_nt": 1, "tokenize_lnfold": 1, "tokenize_split_rounds": 0, "tokenize_vq_head": 1, "tokenize_tile_stats": 0, "gemm_store": 128, "gemm64_xcd": 1, "gemm_small": 1, "attn_small": 1}
 
 
 def apply(spec):
