@@ -924,9 +924,9 @@ __global__ __launch_bounds__(64 * (CM * CN + PW), 1) void gemms_kernel(GemmParam
     constexpr int A_BYTES = TM * BK * 2, W_BYTES = TN * BK * 2, ST = A_BYTES + W_BYTES;     // one ring stage: A tile | W tile, 128-byte rows
     constexpr int PA = TM / 8, PN = TN / 8, PP = (PA + PN) / PW;                            // 1 KiB pieces (8 rows) per stage / per producer
     static_assert((PA + PN) % PW == 0 && PA % PW == 0, "pieces deal evenly over the producers");
-    // A ring slot holds KPS = 2 consecutive K-tiles and there is ONE barrier per slot: what paces one image's K loop is the barrier round
-    // trip itself (~400 cycles per K-tile whether four or eight producers feed it and whether or not the consumers double-buffer their
-    // fragments), so a slot carries twice the MFMAs per barrier.
+    // A ring slot holds KPS = 2 consecutive K-tiles and there is ONE barrier per slot (half the barrier round trips per K-tile).  Measured
+    // neutral against one K-tile per slot, as were eight producers against four and double-buffered fragments: ~190 ns per K-tile at one
+    // image whatever is varied inside the workgroup (LABNOTES round 6) - kept because it costs nothing.
     constexpr int KPS = 2, SLOT = KPS * ST;
     constexpr int NS = SLOT <= 24576 ? 5 : SLOT <= 32768 ? 4 : 3;                             // 120 / 128 / 144 KiB of ring
     constexpr int NT = 64 * (NC + PW);

@@ -1,0 +1,307 @@
+// Probe (tools/probes): the structural bet of round 6 as a stand-alone K loop - compute waves that issue NO operand requests.
+//
+//   block tile 128 (M) x 256 (N) x 64 (K); 8 compute waves of 64 x 64 (2 along M x 4 along N; 64 accumulator registers each) + 4 PRODUCER waves
+//   that issue every LDS-DMA request = 12 waves, 3 per SIMD (<= 168 registers); ring of three 48 KiB stages (A 16 KiB | W 32 KiB, the product's
+//   XOR-swizzled 128-byte rows); one counted wait + ONE barrier per K-tile; persistent workgroups (one per CU) walking the product's XCD-contiguous
+//   grouped tile order, the producers running across tile boundaries (a tile's first K-tiles are requested while the previous tile is multiplied).
+//   MFMA orientation, fragment layout and k order are those of seed_amd/csrc/gemm_bf16.hip (each output element one k-ordered chain).
+//
+// Prediction written before the first run: LABNOTES.md, round 6.  Prints TFLOP/s of the K loop alone (STORE = 0: one dword per lane and tile keeps the
+// accumulators live) and with a plain bf16 store of C, on the ViT QKV shape (M = 65792, K = 1408, N = 4224), and checks C against a host fp64
+// reference on a small shape.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/probes/gemm_producer_probe.bin tools/probes/gemm_producer_probe.hip && tools/probes/gemm_producer_probe.bin
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define DEVINL __device__ __forceinline__
+
+constexpr int BK = 64, TM = 128, TN = 256, NCW = 8, NPW = 4, NS = 3;
+constexpr int A_BYTES = TM * BK * 2, W_BYTES = TN * BK * 2, ST = A_BYTES + W_BYTES;      // 16 KiB | 32 KiB
+constexpr int PIECES = (A_BYTES + W_BYTES) / 1024, PP = PIECES / NPW;                    // 48 pieces of 1 KiB, 12 per producer
+constexpr int LDS_BYTES = NS * ST;
+
+DEVINL int swzA(int row) { return (row >> 1) & 7; }
+DEVINL int swzW(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+DEVINL uint32_t pack2bf(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    f2 v = {lo, hi};
+    b2 r = __builtin_convertvector(v, b2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+struct P {
+    const bf16_t* A; const bf16_t* W; bf16_t* C;
+    int M, N, K, lda, ldw, ldc, tiles_m, tiles_n, group_m;
+    unsigned* sink;
+};
+
+// the product's tile order: XCD x takes the x-th eighth of the grouped (group_m m-tiles x all n-tiles) order, workgroup idx of the XCD tiles idx, idx + G, ...
+DEVINL int tile_count(const P& p, int& cs, int& idx, int& G) {
+    const int nt = p.tiles_m * p.tiles_n, bid = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = bid & 7;
+    idx = bid >> 3;
+    cs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int n_x = q + (xcd < r ? 1 : 0);
+    G = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int n = (n_x - idx + G - 1) / G;
+    return n < 0 ? 0 : n;
+}
+DEVINL void tile_coords(const P& p, int t, int& tm, int& tn) {
+    const int gsize = p.group_m * p.tiles_n, gid = t / gsize, first_m = gid * p.group_m;
+    const int gm = min(p.tiles_m - first_m, p.group_m), in_g = t - gid * gsize;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+}
+
+template <int STORE>
+__global__ __launch_bounds__(64 * (NCW + NPW), 1) void gemm_p_kernel(const P p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = p.K / BK;
+    int cs, idx, G;
+    const int ntiles = tile_count(p, cs, idx, G);
+    const int nstages = ntiles * nk;
+    if (wave >= NCW) {
+        // ---- producers: stage s = (tile s / nk, K-tile s % nk) into ring slot s % NS; requests run NS - 1 stages ahead, across tile boundaries
+        const int pw = wave - NCW;
+        uint32_t off[PP];
+        bool isA[PP];
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int i = pw + NPW * j;                              // piece i: rows 8 i .. 8 i + 7 of [A tile | W tile]
+            isA[j] = i < A_BYTES / 1024;
+            const int row = 8 * (isA[j] ? i : i - A_BYTES / 1024) + (lane >> 3), c = lane & 7;
+            off[j] = isA[j] ? 2u * ((uint32_t)row * (uint32_t)p.lda + 8u * (uint32_t)(c ^ swzA(row)))
+                            : 2u * ((uint32_t)row * (uint32_t)p.ldw + 8u * (uint32_t)(c ^ swzW(row)));
+        }
+        int cur_tile = -1;
+        __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000), rsW = rsA;
+        auto stage = [&](int s) {
+            const int slot = s % NS;                                 // (the ring slot is that of the stage's own number ...)
+            if (s >= nstages) s = nstages - 1;                       // (... its data, beyond the end, a re-fetch of the last stage: position-free tail)
+            const int tl = s / nk, kt = s - tl * nk;
+            if (tl != cur_tile) {                                    // the tile of a request is a wave-uniform descriptor: rows beyond M / N read as zero
+                cur_tile = tl;
+                int tm, tn;
+                tile_coords(p, cs + idx + tl * G, tm, tn);
+                const long long ra = (long long)(p.M - tm * TM) * p.lda * 2, rw = (long long)(p.N - tn * TN) * p.ldw * 2;
+                rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)tm * TM * p.lda), 0, (int)(ra > 0x7fffffffLL ? 0x7fffffffLL : ra), 0x00020000);
+                rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)tn * TN * p.ldw), 0, (int)(rw > 0x7fffffffLL ? 0x7fffffffLL : rw), 0x00020000);
+            }
+            char* base = smem + slot * ST;
+            const int koff = 2 * kt * BK;
+#pragma unroll
+            for (int j = 0; j < PP; ++j) {
+                const int i = pw + NPW * j;
+#ifdef NO_DMA
+                if (s > NS) continue;                                // timing only: no operand requests after the first stages
+#endif
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isA[j] ? rsA : rsW, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, (int)off[j], koff, 0, 0);
+            }
+        };
+        if (nstages > 0) {
+            for (int s = 0; s < NS - 1; ++s) stage(s);
+            for (int s = 0; s < nstages; ++s) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * (NS - 2)) : "memory");     // stage s has landed (the younger one stays in flight)
+                __builtin_amdgcn_s_barrier();                        // published; the compute waves retired their reads of stage s - 1
+                stage(s + NS - 1);
+            }
+        }
+        return;
+    }
+    // ---- compute waves
+    const int wm = wave >> 2, wn = wave & 3;
+    int rdA[4], rdW[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int ra = 64 * wm + 16 * mi + li;
+        rdA[mi] = ra * 128 + ((g ^ swzA(ra)) << 4);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rw = 64 * wn + 16 * (li >> 2) + 4 * t + (li & 3);
+        rdW[t] = A_BYTES + rw * 128 + ((g ^ swzW(rw)) << 4);
+    }
+    // Fragments double-buffered ACROSS the barrier (second form of the probe: in the first, both compute waves of a SIMD came out of the barrier
+    // together, waited for their reads together and then queued for the matrix pipe together - 2 x (~250 idle + 512 busy) cycles per K-tile):
+    //   barrier s | request f0 = k-step 0 of stage s | MFMA f1 (k-step 1 of stage s - 1, registers only) | wait | request f1 = k-step 1 | MFMA f0
+    bf16x8 a0[4], w0[4], a1[4], w1[4];
+    f32x4 acc[4][4];
+    auto zero = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto rd = [&](bf16x8 (&a)[4], bf16x8 (&w)[4], const char* sb, int ks) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a[mi] = *(const bf16x8*)(sb + (rdA[mi] ^ (ks << 6)));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = *(const bf16x8*)(sb + (rdW[t] ^ (ks << 6)));
+    };
+    auto mm = [&](const bf16x8 (&a)[4], const bf16x8 (&w)[4]) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+    };
+    auto finish = [&](int tl) {
+        int tm, tn;
+        tile_coords(p, cs + idx + tl * G, tm, tn);
+        if (STORE) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = tm * TM + 64 * wm + 16 * mi + li, col = tn * TN + 64 * wn + 16 * g;
+                if (row < p.M && col + 16 <= p.N) {
+                    uint4 lo, hi;
+                    lo.x = pack2bf(acc[mi][0][0], acc[mi][0][1]); lo.y = pack2bf(acc[mi][0][2], acc[mi][0][3]);
+                    lo.z = pack2bf(acc[mi][1][0], acc[mi][1][1]); lo.w = pack2bf(acc[mi][1][2], acc[mi][1][3]);
+                    hi.x = pack2bf(acc[mi][2][0], acc[mi][2][1]); hi.y = pack2bf(acc[mi][2][2], acc[mi][2][3]);
+                    hi.z = pack2bf(acc[mi][3][0], acc[mi][3][1]); hi.w = pack2bf(acc[mi][3][2], acc[mi][3][3]);
+                    bf16_t* cp = p.C + (size_t)row * p.ldc + col;
+                    *(uint4*)cp = lo;
+                    *(uint4*)(cp + 8) = hi;
+                }
+            }
+        } else {
+            float t = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) t += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+            if (t == 1234.5678f) p.sink[0] = 1;                      // (keeps the accumulators live; never true)
+        }
+    };
+    zero();
+    int kt = 0, tl = 0;
+    for (int s = 0; s < nstages; ++s) {
+        __builtin_amdgcn_s_barrier();
+        const char* sb = smem + (s % NS) * ST;
+        rd(a0, w0, sb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) mm(a1, w1);                                     // k-step 1 of the previous stage (its tile's accumulators are still current)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0 && kt == 0) {                                    // that stage was the last of tile tl - 1
+            finish(tl - 1);
+            zero();
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): f0 has landed
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef HALF_READS
+        {   // timing only: k-step 1 re-uses k-step 0's W fragments (12 instead of 16 fragment reads per K-tile)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a1[mi] = *(const bf16x8*)(sb + (rdA[mi] ^ 64));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w1[t] = w0[t];
+        }
+#else
+        rd(a1, w1, sb, 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a0, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                        // f1 is in registers before the next barrier lets the slot be restaged
+        __builtin_amdgcn_sched_barrier(0);
+        if (++kt == nk) { kt = 0; ++tl; }
+    }
+    if (nstages > 0) {
+        mm(a1, w1);
+        finish(ntiles - 1);
+    }
+}
+
+static uint16_t f2bf_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u = (u + (0x7FFFu + ((u >> 16) & 1u))) >> 16;
+    return (uint16_t)u;
+}
+static float bf2f_host(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+template <int STORE>
+static float run(const P& p, int grid, int iters) {
+    hipFuncSetAttribute((const void*)gemm_p_kernel<STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_p_kernel<STORE>), dim3(grid), dim3(64 * (NCW + NPW)), LDS_BYTES, 0, p);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_p_kernel<STORE>), dim3(grid), dim3(64 * (NCW + NPW)), LDS_BYTES, 0, p);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / iters;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    // ---- correctness on a small ragged shape against fp64 on the host
+    {
+        const int M = 300, N = 768, K = 256;
+        std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
+        srand(1);
+        for (auto& v : hA) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 2.f);
+        for (auto& v : hW) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 0.2f);
+        bf16_t *dA, *dW, *dC; unsigned* sink;
+        hipMalloc(&dA, hA.size() * 2); hipMalloc(&dW, hW.size() * 2); hipMalloc(&dC, (size_t)M * N * 2); hipMalloc(&sink, 64);
+        hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+        hipMemset(dC, 0, (size_t)M * N * 2);
+        P p{dA, dW, dC, M, N, K, K, K, N, (M + TM - 1) / TM, (N + TN - 1) / TN, 6, sink};
+        const int nt = p.tiles_m * p.tiles_n;
+        run<1>(p, nt < cus ? nt : cus, 1);
+        std::vector<uint16_t> hC((size_t)M * N);
+        hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
+        double worst = 0;
+        int bad = 0;
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) {
+                double s = 0;
+                for (int k = 0; k < K; ++k) s += (double)bf2f_host(hA[(size_t)m * K + k]) * bf2f_host(hW[(size_t)n * K + k]);
+                const double e = fabs(bf2f_host(hC[(size_t)m * N + n]) - s), tol = 0.01 * fabs(s) + 2e-2;
+                if (e > tol) ++bad;
+                if (e > worst) worst = e;
+            }
+        printf("check %dx%dx%d: %d of %d outside tolerance, worst abs err %.4f\n", M, N, K, bad, M * N, worst);
+        hipFree(dA); hipFree(dW); hipFree(dC); hipFree(sink);
+#if !defined(HALF_READS) && !defined(NO_DMA)
+        if (bad) return 1;
+#endif
+    }
+    // ---- the ViT QKV shape, random operands
+    const int M = 65792, N = 4224, K = 1408;
+    std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
+    srand(2);
+    for (auto& v : hA) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 4.f);       // ~ LayerNorm-ed activations
+    for (auto& v : hW) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 0.08f);
+    bf16_t *dA, *dW, *dC; unsigned* sink;
+    hipMalloc(&dA, hA.size() * 2); hipMalloc(&dW, hW.size() * 2); hipMalloc(&dC, (size_t)M * N * 2); hipMalloc(&sink, 64);
+    hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+    const double flops = 2.0 * M * N * K;
+    for (int gm : {6, 12, 3}) {
+        P p{dA, dW, dC, M, N, K, K, K, N, (M + TM - 1) / TM, (N + TN - 1) / TN, gm, sink};
+        for (int rep = 0; rep < 2; ++rep) {
+            const float k_ms = run<0>(p, cus, 20), s_ms = run<1>(p, cus, 20);
+            printf("QKV shape, group_m %2d: K loop alone %.4f ms = %.1f TFLOP/s | with plain bf16 stores %.4f ms = %.1f TFLOP/s\n", gm, k_ms, flops / k_ms / 1e9,
+                   s_ms, flops / s_ms / 1e9);
+        }
+    }
+    return 0;
+}
