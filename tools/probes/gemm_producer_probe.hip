@@ -93,6 +93,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void gemm_p_kernel(const P p) 
                 cur_tile = tl;
                 int tm, tn;
                 tile_coords(p, cs + idx + tl * G, tm, tn);
+#ifdef HOT
+                tm = tn = 0;                                         // timing only: every workgroup streams the SAME operand panels (L2-resident)
+#endif
                 const long long ra = (long long)(p.M - tm * TM) * p.lda * 2, rw = (long long)(p.N - tn * TN) * p.ldw * 2;
                 rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)tm * TM * p.lda), 0, (int)(ra > 0x7fffffffLL ? 0x7fffffffLL : ra), 0x00020000);
                 rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)tn * TN * p.ldw), 0, (int)(rw > 0x7fffffffLL ? 0x7fffffffLL : rw), 0x00020000);
@@ -105,13 +108,20 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void gemm_p_kernel(const P p) 
 #ifdef NO_DMA
                 if (s > NS) continue;                                // timing only: no operand requests after the first stages
 #endif
+#ifdef W_DIRECT
+                if (!isA[j]) continue;                               // W does not pass through the LDS at all (compute waves load its fragments)
+#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(isA[j] ? rsA : rsW, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, (int)off[j], koff, 0, 0);
             }
         };
         if (nstages > 0) {
             for (int s = 0; s < NS - 1; ++s) stage(s);
             for (int s = 0; s < nstages; ++s) {
+#ifdef W_DIRECT
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_BYTES / 1024 / NPW) * (NS - 2)) : "memory");
+#else
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * (NS - 2)) : "memory");     // stage s has landed (the younger one stays in flight)
+#endif
                 __builtin_amdgcn_s_barrier();                        // published; the compute waves retired their reads of stage s - 1
                 stage(s + NS - 1);
             }
@@ -183,6 +193,56 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void gemm_p_kernel(const P p) 
     };
     zero();
     int kt = 0, tl = 0;
+#ifdef W_DIRECT
+    // Third form (timing only - W is read as if it were packed fragment-major, 1 KiB per fragment: values are wrong): the W fragments go from
+    // global memory straight into the MFMA operand registers of the wave that uses them, one K-tile ahead; only A passes through the LDS.
+    {
+        const size_t wbytes = (size_t)p.N * p.ldw * 2 - 65536;
+        auto wfrag = [&](int tile_lin, int kt_, int ks, int t) {
+            int tm, tn;
+            tile_coords(p, tile_lin, tm, tn);
+            const size_t off = ((((size_t)tn * nk + kt_) * 32 + wn * 8 + ks * 4 + t) * 1024) % wbytes;
+            return *(const bf16x8*)((const char*)p.W + (off & ~(size_t)1023) + lane * 16);
+        };
+        bf16x8 wc[2][4], wnx[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wc[ks][t] = wfrag(cs + idx, 0, ks, t);
+        for (int s = 0; s < nstages; ++s) {
+            __builtin_amdgcn_s_barrier();
+            const char* sb = smem + (s % NS) * ST;
+            const int kn = kt + 1 == nk ? 0 : kt + 1, tln = kt + 1 == nk ? tl + 1 : tl;
+            if (s + 1 < nstages) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) wnx[ks][t] = wfrag(cs + idx + tln * G, kn, ks, t);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) a0[mi] = *(const bf16x8*)(sb + (rdA[mi] ^ (ks << 6)));
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ks][ni], a0[mi], acc[mi][ni], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (++kt == nk) {
+                kt = 0;
+                finish(tl);
+                zero();
+                ++tl;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wc[ks][t] = wnx[ks][t];
+        }
+        return;
+    }
+#endif
     for (int s = 0; s < nstages; ++s) {
         __builtin_amdgcn_s_barrier();
         const char* sb = smem + (s % NS) * ST;
@@ -280,7 +340,7 @@ int main() {
             }
         printf("check %dx%dx%d: %d of %d outside tolerance, worst abs err %.4f\n", M, N, K, bad, M * N, worst);
         hipFree(dA); hipFree(dW); hipFree(dC); hipFree(sink);
-#if !defined(HALF_READS) && !defined(NO_DMA)
+#if !defined(HALF_READS) && !defined(NO_DMA) && !defined(HOT) && !defined(W_DIRECT)
         if (bad) return 1;
 #endif
     }
