@@ -399,12 +399,13 @@ def cpu_baseline(n_images):
     cores = max(sweep, key=sweep.get)
     torch.set_num_threads(cores)
     main_fn(img[:1])
-    dt = _timed(main_fn, img)
+    runs = [_timed(main_fn, img) for _ in range(3)]                       # three passes over the sample, the median reported (VERDICT r5 weak 10:
+    dt = sorted(runs)[1]                                                  # one 8-image batch read 1.89-2.02 img/s across runs)
     port_fn(img[:1])
     dt_port = dt if ref_fn is None else _timed(port_fn, img)
     if ref_fn is not None:
         res = {"value": round(n_images / dt, 3), "unit": "images/s", "cores": cores, "kind": "reference",
-               "sample": f"{n_images} images (one batch) of the same synthetic 224x224 workload, the reference's own modules from {origin} "
+               "sample": f"{n_images} images (one batch, median of three passes) of the same synthetic 224x224 workload, the reference's own modules from {origin} "
                          f"(fp32, dependency shims only), torch CPU with {cores} of {ncpu} host threads (fastest of the sweep), {dt:.1f} s; "
                          f"oracle port on the same sample: {n_images / dt_port:.3f} images/s",
                "port_value": round(n_images / dt_port, 3)}
@@ -415,6 +416,7 @@ def cpu_baseline(n_images):
         if ref_err:
             res["reference_error"] = ref_err
     res["thread_sweep_images_per_s"] = {str(k): v for k, v in sweep.items()}
+    res["sample_runs_s"] = [round(r, 2) for r in runs]
     return res
 
 
