@@ -909,14 +909,15 @@ __global__ __launch_bounds__(PROD ? 512 : 256, NS <= 4 ? 2 : 1) void gemm64_kern
 }
 
 // ======================================================================================================
-// Kernel "gemms": the small-M kernel in three tile shapes with EIGHT producer waves (round 6).  What bounds one image's GEMMs is not
-// memory latency (average L2 round trip 420 cycles, profiles/r06_pmc_stalls_b1_*.json) and not the consumers (double-buffered fragment
-// reads changed nothing) but the rate at which a CU's waves can ISSUE operand requests: a wave gets one 1 KiB LDS-DMA request accepted per
-// ~100 cycles, so gemm64's four producers move a 16 KiB K-tile in ~400 cycles where the L1 -> LDS path (64 B per clock) needs 256
-// (tools/probes/operand_feed_probe.hip: 4 waves 74 GB/s per CU, 8 waves 104, 16 waves 124).  And 64x64 tiles put 330 (QKV) / 480 (fc1)
-// tiles on 256 CUs: the CUs that get two decide the launch.  So: 8 producer waves, one workgroup per CU, and per GEMM the shape whose
-// worst CU moves the fewest bytes - 64x64 (CM = 4, CN = 1), 128x64 (8, 1: QKV at M = 257 is 198 tiles), 64x128 (4, 2: fc1 240 tiles) or
-// 32x64 (2, 1 with four producers: proj / fc2 at M = 257 are 110 tiles of 64x64 - 146 CUs idle - and 198 of 32x64).
+// Kernel "gemms": the small-M kernel in four tile shapes (round 6).  One image is M = 257: 64x64 tiles put 330 (QKV) / 480 (fc1) tiles
+// on 256 CUs - the CUs that get two decide the launch - and 110 (proj, fc2) leave 146 CUs idle.  So: one workgroup per CU and, per GEMM, the
+// shape whose busiest CU streams the fewest operand bytes - 64x64 (CM = 4, CN = 1), 128x64 (8, 1: QKV 198 tiles), 64x128 (4, 2: fc1 240
+// tiles) or 32x64 (2, 1: proj / fc2 198 tiles; the Q-Former's M = 32 GEMMs stop staging 32 rows of padding).  Dedicated producer waves
+// (8, or 4 for 32x64) issue every LDS-DMA request; a ring slot holds two K-tiles.
+// What was learnt building it (LABNOTES round 6): a launch costs 5.6 us + ~150-190 ns per K-tile at one image, and the per-K-tile time did
+// not move with the number of producers (4 / 8), the number of barriers (one or two K-tiles per slot), double-buffered fragment reads or
+// L2 touch prefetch (slower) - memory latency is not it (average L2 round trip 420 cycles, profiles/r06_pmc_stalls_b1_*.json); what moved
+// the pass was tile COUNT and bytes per CU.
 // Consumer wave = 16 rows x 64 columns exactly as in gemm64 (same fragment layout, same k-ordered chain, same epilogue): bit-identical.
 template <int EPI, bool LNF, int CM, int CN, int PW>
 __global__ __launch_bounds__(64 * (CM * CN + PW), 1) void gemms_kernel(GemmParams p) {
