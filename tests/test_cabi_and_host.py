@@ -244,6 +244,19 @@ def test_data_parallel_gather_gloo_world2(tmp_path):
         assert p.returncode == 0 and f"ok {r}" in o, o
 
 
+def test_one_image_roofline_bytes_match_the_state_dict():
+    """extra.latency_b1.tokenize.roofline divides by the 16-bit bytes of every weight one tokenize pass reads (bench.tokenizer_weight_bytes:
+    2.18 GB at full size): the closed form must agree with the encode-path tensors of the synthetic state dict (here at MID size)."""
+    import bench
+    from seed_amd import config as C
+    from seed_amd.weights import make_tokenizer_state_dict
+    cfg = C.MID
+    sd = make_tokenizer_state_dict(cfg, seed=0)
+    actual = 2 * sum(v.numel() for v in sd.values())
+    assert abs(bench.tokenizer_weight_bytes(cfg) - actual) / actual < 0.01, (bench.tokenizer_weight_bytes(cfg), actual)
+    assert abs(bench.tokenizer_weight_bytes(C.SEED2) / 1e9 - 2.18) < 0.01
+
+
 def test_bench_gpus_flag_relaunches_as_n_ranks():
     """`python bench.py --gpus N` outside a launcher used to run one rank and print n_gpus: 1.  It now re-executes
     itself under torch.distributed.run with N processes; inside a launcher (WORLD_SIZE set) or at N = 1 it runs in place, and a
